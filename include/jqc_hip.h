@@ -1,0 +1,82 @@
+/*
+ * jqc_hip.h -- C ABI of libjqc_hip.so, the MI355X (gfx950) backend of the JoltQC hot path.
+ *
+ * The reference has no compiled extension: its "FFI" is CuPy RawModule/RawKernel, i.e. "compile this
+ * class-specialised source, give me a launchable handle, launch it on raw device pointers"
+ * (/root/reference/jqc/backend/jk_1q1t.py:117-148, jk_tasks.py:40-109, linalg_helper.py:125-211).
+ * Each entry point below replaces one of those generator/launcher pairs.  Plain pointers and sizes
+ * only; all pointers named *_d are device pointers owned by the caller; kernels accumulate into
+ * vj/vk (caller zero-fills), never allocate, free or retain them.  `stream` is a hipStream_t
+ * (NULL = default stream).  Every function returns 0 on success and a negative code on failure;
+ * jqc_last_error() returns the message.  Launches are asynchronous.
+ */
+#ifndef JQC_HIP_H
+#define JQC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JQC_BASIS_STRIDE 12 /* [x,y,z,ao_loc | c0,e0,c1,e1,c2,e2 | nprim, l]  (jqc/constants.py:33, basis.py:280-371) */
+#define JQC_LMAX 4          /* jqc/constants.py:21 */
+#define JQC_NPRIM_MAX 3     /* jqc/constants.py:26 */
+
+/* algorithm ids for jqc_gen_jk_kernel (reference router: jqc/backend/jk.py:57-115) */
+#define JQC_ALGO_1Q1T 0 /* one quartet per lane        (reference jk_1q1t.py / jk/1q1t.cu)  */
+#define JQC_ALGO_TILE 1 /* lane-group per quartet, LDS Fock tiles (replaces jk_1qnt.py / jk/1qnt.cu) */
+
+const char* jqc_last_error(void);
+const char* jqc_version(void);
+
+/* Runtime set-up.  src_dir holds the kernel sources (joltqc_amd/csrc/kernels), cache_dir receives
+ * the gfx950 code objects (one .hsaco per class/variant; replaces CuPy's cubin cache, examples/04). */
+int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir);
+
+/* Upload the packed Rys tables (layout: joltqc_amd/backend/rys.py) to the current device. */
+int jqc_set_rys_tables(const double* blob_host, size_t ndoubles);
+
+/* gen_jk_kernel (jqc/backend/jk.py:57): returns a handle >= 0.  With compile_only != 0 the code object
+ * is built into the cache (works without a GPU) and not loaded. */
+int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int rys_lr, int fp32, int algo,
+                      int compile_only);
+
+/* Launch of a generated J/K kernel (argument order of rys_1q1t_vjk, jqc/backend/jk/1q1t.cu:45-52):
+ *   basis_d  real[nbas*12], dm_d real[n_dm*nao*nao], vj_d/vk_d double[n_dm*nao*nao] (NULL if unused),
+ *   quartets_d ushort4[...]; the task count is read ON DEVICE from *ntasks_d (no host sync);
+ *   ntasks_max bounds the grid; qstride = +1 (list grows upward) or -1 (list grows downward). */
+int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, double* vj_d, double* vk_d,
+                  double omega, const void* quartets_d, const uint32_t* ntasks_d, int64_t ntasks_max,
+                  int qstride, int n_dm, void* stream);
+
+/* Screening + queue generation (replaces screen_jk_tasks, jqc/backend/jk/screen_jk_tasks.cu:75-340).
+ * One launch handles a whole chunk of "screen tasks"; task t covers the rectangle
+ * pairs[ij0 .. ij0+nij) x pairs[kl0 .. kl0+nkl) and appends survivors to region `cls`:
+ *   tasks_d      int32[ntasks][8] = {ij0, nij, kl0, nkl, cls, blk0, 0, 0}, blk0 = first block of the task
+ *   pair_sh_d    uint32[npairs]   = ish<<16 | jsh  (ish >= jsh), pair_q_d float[npairs] = log Schwarz bound
+ *   log_dm_d     float[nbas*nbas] = log max|D| per shell block  (max_block_pooling + log)
+ *   region_d     int64[ncls][2]   = {begin, end} of each class region in queue_d (ushort4 units)
+ *   counters_d   uint32[ncls][2]  = {n_fp64 (appended from begin), n_fp32 (appended down from end)}
+ * Predicate (natural-log float32, screen_jk_tasks.cu:202-261):
+ *   keep if ish*nbas+jsh >= ksh*nbas+lsh and q_ij + q_kl + d_large > log_cutoff_fp32 where
+ *   d_large = max(-36.8, [do_k] d_ik,d_jk,d_il,d_jl, [do_j] d_ij,d_kl);  FP64 list if > log_cutoff_fp64. */
+int jqc_screen_jk_tasks(const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* pair_sh_d,
+                        const float* pair_q_d, const float* log_dm_d, int nbas, int do_j, int do_k,
+                        float log_cutoff_fp32, float log_cutoff_fp64, float log_max_dm, void* queue_d,
+                        const int64_t* region_d, uint32_t* counters_d, void* stream);
+
+/* max_block_pooling (jqc/backend/linalg_helper.py:125-211): out[I,J] = max_b max_{r in I, c in J} |M[b,r,c]|
+ * over shell blocks given by ao_loc_d int32[nbas+1]; M is double[n_dm,nao,nao]; out float[nbas*nbas]. */
+int jqc_shell_block_max(const double* mat_d, int n_dm, int nao, const int32_t* ao_loc_d, int nbas,
+                        float* out_d, void* stream);
+
+/* Schwarz bounds on device (replaces the libcvhf call in compute_q_matrix, jqc/pyscf/basis.py:840-867):
+ * for each listed pair p = (ish<<16|jsh) with l(ish)=li, l(jsh)=lj:  out[p] = sqrt(max_ab |(ab|ab)|). */
+int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d, int npairs, double omega,
+                double* out_d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

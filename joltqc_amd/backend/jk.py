@@ -1,0 +1,43 @@
+"""Algorithm router for the J/K kernels (role of ``gen_jk_kernel``, /root/reference/jqc/backend/jk.py:57-115).
+
+The reference looks a class key ``1000 li + 100 lj + 10 lk + ll`` up in a per-GPU tuning JSON and
+chooses between its 1q1t and 1qnt kernels.  Here the table is for gfx950: ``ALGO_1Q1T`` (one quartet
+per lane) or ``ALGO_TILE`` (lane group per quartet with LDS Fock tiles); see
+``joltqc_amd/data/gfx950_scheme.json`` when present, otherwise the rule below.
+"""
+import json
+import os
+from functools import lru_cache
+
+from . import lib as _lib
+
+_SCHEME = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "gfx950_scheme.json")
+
+
+@lru_cache(maxsize=1)
+def _table():
+    if os.path.exists(_SCHEME):
+        with open(_SCHEME) as f:
+            return json.load(f)
+    return {}
+
+
+def class_key(ang):
+    li, lj, lk, ll = ang
+    return str(1000 * li + 100 * lj + 10 * lk + ll)
+
+
+def select_algo(ang, fp32=False):
+    t = _table().get("fp32" if fp32 else "fp64", {})
+    v = t.get(class_key(ang))
+    if v is None:
+        return _lib.ALGO_1Q1T
+    return int(v)
+
+
+@lru_cache(maxsize=None)
+def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None, compile_only=False):
+    ang = tuple(int(x) for x in ang)
+    if algo is None:
+        algo = select_algo(ang, fp32)
+    return _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, algo, compile_only)

@@ -1,0 +1,388 @@
+// libjqc_hip.so -- C-ABI host layer + class-independent device kernels (gfx950).
+// Declarations and the reference interfaces each entry point replaces: include/jqc_hip.h.
+//
+// Class-specialised J/K kernels are compiled from joltqc_amd/csrc/kernels/*.hip through hiprtc into
+// per-class gfx950 code objects cached on disk (the MI355X analogue of the reference's
+// CuPy RawModule + cubin cache, /root/reference/jqc/backend/jk_1q1t.py:117-148), then loaded with
+// the HIP module API and launched on caller-provided device pointers.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <vector>
+
+#include "../../include/jqc_hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+std::string g_src_dir, g_cache_dir;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[4096];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(-2, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Kernel {
+    std::string key;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    int li = 0, lj = 0, lk = 0, ll = 0, fp32 = 0, algo = 0, nroots = 1;
+};
+std::vector<Kernel> g_kernels;
+std::map<std::string, int> g_by_key;
+
+// device copies of the Rys tables
+double* g_rys64 = nullptr;
+float* g_rys32 = nullptr;
+std::vector<double> g_rys_host;
+
+bool file_exists(const std::string& p)
+{
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && st.st_size > 0;
+}
+
+std::string read_file(const std::string& p)
+{
+    std::ifstream f(p, std::ios::binary);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+// hiprtc: source file + defines -> code object on disk (atomic rename so concurrent ranks are safe)
+int compile_to(const std::string& src_name, const std::vector<std::string>& defs, const std::string& out)
+{
+    const std::string path = g_src_dir + "/" + src_name;
+    const std::string src = read_file(path);
+    if (src.empty()) return fail(-3, "kernel source %s not found (jqc_set_kernel_dirs?)", path.c_str());
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), src_name.c_str(), 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(-3, "hiprtcCreateProgram failed");
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-ffp-contract=fast",
+                                     "-I" + g_src_dir};
+    for (auto& d : defs) opts.push_back(d);
+    std::vector<const char*> copts;
+    for (auto& o : opts) copts.push_back(o.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n + 1, '\0');
+        hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(-3, "hiprtc compile of %s failed:\n%s", src_name.c_str(), log.c_str());
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    std::string code(n, '\0');
+    hiprtcGetCode(prog, &code[0]);
+    hiprtcDestroyProgram(&prog);
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, ".tmp.%d", (int)getpid());
+    const std::string t = out + tmp;
+    {
+        std::ofstream f(t, std::ios::binary);
+        f.write(code.data(), (std::streamsize)code.size());
+        if (!f) return fail(-3, "cannot write %s", t.c_str());
+    }
+    if (rename(t.c_str(), out.c_str()) != 0) return fail(-3, "cannot rename %s", t.c_str());
+    return 0;
+}
+
+int load_kernel(const std::string& hsaco, const char* entry, Kernel& k)
+{
+    const std::string code = read_file(hsaco);
+    if (code.empty()) return fail(-3, "code object %s missing", hsaco.c_str());
+    HIP_OK(hipModuleLoadData(&k.mod, code.data()));
+    HIP_OK(hipModuleGetFunction(&k.fn, k.mod, entry));
+    return 0;
+}
+
+inline const double* rys_cheb64(int n) { return g_rys64 + (long)g_rys_host[2 * n - 1]; }
+inline const double* rys_large64(int n) { return g_rys64 + (long)g_rys_host[2 * n]; }
+inline const float* rys_cheb32(int n) { return g_rys32 + (long)g_rys_host[2 * n - 1]; }
+inline const float* rys_large32(int n) { return g_rys32 + (long)g_rys_host[2 * n]; }
+
+// ------------------------------------------------------------------------------------------------
+// Device kernels that do not depend on the angular-momentum class
+// ------------------------------------------------------------------------------------------------
+
+// One block = 16 ij pairs x 16 kl pairs of one screen task.  Survivors are compacted with wave
+// ballots (wave64) + one atomic per block and list.
+__global__ void __launch_bounds__(256)
+screen_kernel(const int* __restrict__ tasks, const int ntasks, const unsigned* __restrict__ pair_sh,
+              const float* __restrict__ pair_q, const float* __restrict__ log_dm, const int nbas, const int do_j,
+              const int do_k, const float cut32, const float cut64, const float log_max_dm,
+              ushort4* __restrict__ queue, const long long* __restrict__ region, unsigned* __restrict__ counters)
+{
+    __shared__ int s_task[8];
+    __shared__ unsigned s_cnt[2][4];
+    __shared__ unsigned s_base[2];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        // binary search: last task with blk0 <= blockIdx.x
+        int lo = 0, hi = ntasks - 1;
+        const int b = blockIdx.x;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tasks[mid * 8 + 5] <= b) lo = mid; else hi = mid - 1;
+        }
+        for (int n = 0; n < 8; n++) s_task[n] = tasks[lo * 8 + n];
+    }
+    __syncthreads();
+    const int ij0 = s_task[0], nij = s_task[1], kl0 = s_task[2], nkl = s_task[3], cls = s_task[4];
+    const int lb = blockIdx.x - s_task[5];
+    const int nbk = (nkl + 15) >> 4;
+    const int bij = lb / nbk, bkl = lb - bij * nbk;
+    // pair lists are sorted by q descending: the first pair of each 16-strip carries the strip maximum
+    const float qmax = pair_q[ij0 + bij * 16] + pair_q[kl0 + bkl * 16];
+    if (qmax + log_max_dm <= cut32) return;
+
+    const int ij = bij * 16 + (tid >> 4), kl = bkl * 16 + (tid & 15);
+    int keep = 0;  // 1: fp64 list, 2: fp32 list
+    ushort4 sq = {0, 0, 0, 0};
+    if (ij < nij && kl < nkl) {
+        const unsigned pij = pair_sh[ij0 + ij], pkl = pair_sh[kl0 + kl];
+        const int ish = pij >> 16, jsh = pij & 0xffff, ksh = pkl >> 16, lsh = pkl & 0xffff;
+        if (ish * nbas + jsh >= ksh * nbas + lsh) {
+            const float q = pair_q[ij0 + ij] + pair_q[kl0 + kl];
+            float d = -36.8f;
+            if (do_k) {
+                d = fmaxf(d, log_dm[ish * nbas + ksh]);
+                d = fmaxf(d, log_dm[jsh * nbas + ksh]);
+                d = fmaxf(d, log_dm[ish * nbas + lsh]);
+                d = fmaxf(d, log_dm[jsh * nbas + lsh]);
+            }
+            if (do_j) {
+                d = fmaxf(d, log_dm[ish * nbas + jsh]);
+                d = fmaxf(d, log_dm[ksh * nbas + lsh]);
+            }
+            const float dq = q + d;
+            if (dq > cut32) keep = (dq > cut64) ? 1 : 2;
+            sq.x = ish; sq.y = jsh; sq.z = ksh; sq.w = lsh;
+        }
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const unsigned long long m64 = __ballot(keep == 1), m32 = __ballot(keep == 2);
+    if (lane == 0) {
+        s_cnt[0][wave] = __popcll(m64);
+        s_cnt[1][wave] = __popcll(m32);
+    }
+    __syncthreads();
+    if (tid < 2) {
+        const unsigned tot = s_cnt[tid][0] + s_cnt[tid][1] + s_cnt[tid][2] + s_cnt[tid][3];
+        s_base[tid] = tot ? atomicAdd(&counters[cls * 2 + tid], tot) : 0u;
+    }
+    __syncthreads();
+    if (keep) {
+        const int w = keep - 1;
+        unsigned off = s_base[w];
+        for (int x = 0; x < wave; x++) off += s_cnt[w][x];
+        const unsigned long long m = w ? m32 : m64;
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        const long long pos = w ? region[cls * 2 + 1] - 1 - (long long)off : region[cls * 2] + (long long)off;
+        queue[pos] = sq;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+shell_block_max_kernel(const double* __restrict__ mat, const int n_dm, const int nao, const int* __restrict__ ao_loc,
+                       const int nbas, float* __restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nbas * nbas) return;
+    const int I = idx / nbas, J = idx - I * nbas;
+    const int r0 = ao_loc[I], r1 = ao_loc[I + 1], c0 = ao_loc[J], c1 = ao_loc[J + 1];
+    double m = 0;
+    for (int b = 0; b < n_dm; b++)
+        for (int r = r0; r < r1; r++)
+            for (int c = c0; c < c1; c++) m = fmax(m, fabs(mat[((size_t)b * nao + r) * nao + c]));
+    out[idx] = (float)m;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* jqc_last_error(void) { return g_err.c_str(); }
+const char* jqc_version(void) { return "joltqc_amd 0.1 (gfx950)"; }
+
+int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_src_dir = src_dir ? src_dir : "";
+    g_cache_dir = cache_dir ? cache_dir : "";
+    if (!g_cache_dir.empty()) mkdir(g_cache_dir.c_str(), 0755);
+    return 0;
+}
+
+int jqc_set_rys_tables(const double* blob, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_rys_host.assign(blob, blob + n);
+    std::vector<float> f(n);
+    for (size_t i = 0; i < n; i++) f[i] = (float)blob[i];
+    if (g_rys64) { (void)hipFree(g_rys64); g_rys64 = nullptr; }
+    if (g_rys32) { (void)hipFree(g_rys32); g_rys32 = nullptr; }
+    HIP_OK(hipMalloc((void**)&g_rys64, n * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&g_rys32, n * sizeof(float)));
+    HIP_OK(hipMemcpy(g_rys64, blob, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(g_rys32, f.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int rys_lr, int fp32, int algo,
+                      int compile_only)
+{
+    std::lock_guard<std::mutex> lk_(g_mu);
+    if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
+        return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
+    if (!do_j && !do_k) return fail(-1, "need do_j or do_k");
+    char key[128];
+    snprintf(key, sizeof key, "jk%d_%d%d%d%d_j%dk%d_lr%d_%s", algo, li, lj, lk, ll, do_j, do_k, rys_lr,
+             fp32 ? "f32" : "f64");
+    auto it = g_by_key.find(key);
+    if (it != g_by_key.end() && (compile_only || g_kernels[it->second].fn)) return it->second;
+    const char* src = algo == JQC_ALGO_TILE ? "jk_tile.hip" : "jk_1q1t.hip";
+    const char* entry = algo == JQC_ALGO_TILE ? "jk_tile" : "jk_1q1t";
+    const std::string out = g_cache_dir + "/" + key + ".hsaco";
+    if (!file_exists(out)) {
+        std::vector<std::string> d = {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
+                                      "-DLK=" + std::to_string(lk), "-DLL=" + std::to_string(ll),
+                                      "-DDO_J=" + std::to_string(do_j), "-DDO_K=" + std::to_string(do_k),
+                                      "-DRYS_LR=" + std::to_string(rys_lr), "-DFP32=" + std::to_string(fp32)};
+        int rc = compile_to(src, d, out);
+        if (rc) return rc;
+    }
+    Kernel k;
+    k.key = key;
+    k.li = li; k.lj = lj; k.lk = lk; k.ll = ll; k.fp32 = fp32; k.algo = algo;
+    k.nroots = (li + lj + lk + ll) / 2 + 1;
+    if (!compile_only) {
+        int rc = load_kernel(out, entry, k);
+        if (rc) return rc;
+    }
+    int h;
+    if (it != g_by_key.end()) {
+        h = it->second;
+        g_kernels[h] = k;
+    } else {
+        h = (int)g_kernels.size();
+        g_kernels.push_back(k);
+        g_by_key[key] = h;
+    }
+    return h;
+}
+
+int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, double* vj_d, double* vk_d,
+                  double omega, const void* quartets_d, const uint32_t* ntasks_d, int64_t ntasks_max, int qstride,
+                  int n_dm, void* stream)
+{
+    if (handle < 0 || handle >= (int)g_kernels.size() || !g_kernels[handle].fn)
+        return fail(-1, "invalid kernel handle %d", handle);
+    if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
+    if (ntasks_max <= 0) return 0;
+    const Kernel& k = g_kernels[handle];
+    const int n = k.nroots;
+    float omega_f = (float)omega;
+    const void* cheb = k.fp32 ? (const void*)rys_cheb32(n) : (const void*)rys_cheb64(n);
+    const void* large = k.fp32 ? (const void*)rys_large32(n) : (const void*)rys_large64(n);
+    void* args[] = {&nao, &basis_d, &dm_d, &vj_d, &vk_d, k.fp32 ? (void*)&omega_f : (void*)&omega,
+                    &quartets_d, &ntasks_d, &qstride, &n_dm, &cheb, &large};
+    const int block = 256;
+    int64_t blocks = (ntasks_max + block - 1) / block;
+    const int64_t cap = 256 * 64;  // grid-stride beyond this
+    if (blocks > cap) blocks = cap;
+    HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)blocks, 1, 1, block, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+    return 0;
+}
+
+int jqc_screen_jk_tasks(const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* pair_sh_d,
+                        const float* pair_q_d, const float* log_dm_d, int nbas, int do_j, int do_k,
+                        float log_cutoff_fp32, float log_cutoff_fp64, float log_max_dm, void* queue_d,
+                        const int64_t* region_d, uint32_t* counters_d, void* stream)
+{
+    if (ntasks <= 0 || nblocks <= 0) return 0;
+    hipLaunchKernelGGL(screen_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, tasks_d, ntasks, pair_sh_d,
+                       pair_q_d, log_dm_d, nbas, do_j, do_k, log_cutoff_fp32, log_cutoff_fp64, log_max_dm,
+                       (ushort4*)queue_d, (const long long*)region_d, counters_d);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int jqc_shell_block_max(const double* mat_d, int n_dm, int nao, const int32_t* ao_loc_d, int nbas, float* out_d,
+                        void* stream)
+{
+    const int n = nbas * nbas;
+    hipLaunchKernelGGL(shell_block_max_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mat_d, n_dm,
+                       nao, ao_loc_d, nbas, out_d);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d, int npairs, double omega,
+                double* out_d, void* stream)
+{
+    if (npairs <= 0) return 0;
+    if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
+    Kernel* kp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk_(g_mu);
+        const int lr = omega > 0 ? 1 : 0;
+        char key[64];
+        snprintf(key, sizeof key, "schwarz_%d%d_lr%d", li, lj, lr);
+        auto it = g_by_key.find(key);
+        if (it == g_by_key.end()) {
+            const std::string out = g_cache_dir + "/" + key + ".hsaco";
+            if (!file_exists(out)) {
+                int rc = compile_to("schwarz.hip", {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
+                                                    "-DRYS_LR=" + std::to_string(lr)}, out);
+                if (rc) return rc;
+            }
+            Kernel k;
+            k.key = key;
+            k.nroots = li + lj + 1;
+            int rc = load_kernel(out, "schwarz", k);
+            if (rc) return rc;
+            g_kernels.push_back(k);
+            g_by_key[key] = (int)g_kernels.size() - 1;
+            it = g_by_key.find(key);
+        }
+        kp = &g_kernels[it->second];
+    }
+    const int n = kp->nroots;
+    const double* cheb = rys_cheb64(n);
+    const double* large = rys_large64(n);
+    void* args[] = {&basis_d, &pair_sh_d, &npairs, &omega, &out_d, &cheb, &large};
+    HIP_OK(hipModuleLaunchKernel(kp->fn, (unsigned)((npairs + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args,
+                                 nullptr));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+"""``joltqc_amd.pyscf.apply(mf)`` -- the drop-in boundary.
+
+Same contract as ``jqc.pyscf.apply`` (/root/reference/jqc/pyscf/__init__.py:121-254): patches, in
+place, ``get_jk / get_j / get_k / get_veff`` (and for RKS ``_numint.get_rho / nr_rks / nr_nlc_vxc``,
+``grids.build``) of an RHF/RKS-like mean-field object with MI355X kernels, wraps ``reset`` and
+``as_scanner`` so geometry changes re-apply, and returns the object.
+
+Difference forced by the platform: GPU4PySCF does not exist on ROCm, so ``obj.to_gpu()`` is only
+attempted when the object offers it AND gpu4pyscf is importable; otherwise the CPU PySCF object
+(or any object with ``.mol`` and ``istype``) is patched directly, NumPy in / NumPy out at the
+boundary with device buffers kept inside the closures ("Callers").
+"""
+from functools import wraps
+from types import MethodType
+from typing import Any, Dict, Optional
+
+__all__ = ["apply", "reset", "get_default_config"]
+
+
+def get_default_config() -> Dict[str, Any]:
+    """Default cutoffs (reference __init__.py:100-118)."""
+    return {
+        "jk": {"cutoff_fp32": None, "cutoff_fp64": None},   # None -> obj.direct_scf_tol
+        "dft": {"cutoff_fp32": 1e-13, "cutoff_fp64": 1e-6},
+    }
+
+
+def create_reset_function(original_reset, config):
+    @wraps(original_reset)
+    def reset(self, mol=None):
+        mf = original_reset(self, mol)
+        return apply(mf, config)
+    return reset
+
+
+def create_scanner_wrapper(original_as_scanner, config):
+    @wraps(original_as_scanner)
+    def as_scanner(self, **kwargs):
+        scanner = original_as_scanner(self, **kwargs)
+        scanner._joltqc_applied = True
+        if hasattr(scanner, "reset"):
+            original_scanner_reset = scanner.reset.__func__
+            scanner.reset = MethodType(create_reset_function(original_scanner_reset, config), scanner)
+        return scanner
+    return as_scanner
+
+
+def reset(obj, mol=None):
+    """Module-level convenience named in the reference's ``__all__`` (never defined there)."""
+    return obj.reset(mol)
+
+
+def _is(obj, name):
+    return hasattr(obj, "istype") and obj.istype(name)
+
+
+def apply(obj, config: Optional[Dict[str, Any]] = None):
+    """Patch ``obj`` in place with the MI355X J/K (and DFT grid) kernels and return it."""
+    is_device_obj = "gpu4pyscf" in obj.__class__.__module__
+    if not is_device_obj and hasattr(obj, "to_gpu"):
+        try:
+            import gpu4pyscf  # noqa: F401  (absent on ROCm images)
+            obj = obj.to_gpu()
+            is_device_obj = True
+        except ImportError:
+            pass
+
+    if config is None:
+        config = get_default_config()
+    jk_cutoff_fp32 = config.get("jk", {}).get("cutoff_fp32")
+    jk_cutoff_fp64 = config.get("jk", {}).get("cutoff_fp64")
+    dft_cutoff_fp32 = config.get("dft", {}).get("cutoff_fp32")
+    dft_cutoff_fp64 = config.get("dft", {}).get("cutoff_fp64")
+    if jk_cutoff_fp32 is None:
+        jk_cutoff_fp32 = getattr(obj, "direct_scf_tol", 1e-12)
+    if jk_cutoff_fp64 is None:
+        jk_cutoff_fp64 = getattr(obj, "direct_scf_tol", 1e-12)
+    if dft_cutoff_fp32 is None:
+        dft_cutoff_fp32 = 1e-13
+    if dft_cutoff_fp64 is None:
+        dft_cutoff_fp64 = 1e-6
+
+    if hasattr(obj, "istype") and not obj.istype("RHF"):
+        return obj
+
+    from . import jk as _jk
+    from .basis import BasisLayout
+    from ..constants import TILE
+
+    # the reference builds two layouts (alignment 1 for DFT, TILE for JK, __init__.py:188-189); the
+    # pair-list screening of this build needs no tile padding, the argument is kept for API parity
+    basis_layout_jk = BasisLayout.from_mol(obj.mol, alignment=1)
+    obj._jqc_basis_layout = basis_layout_jk
+    numpy_boundary = not is_device_obj
+
+    if _is(obj, "RKS"):
+        try:
+            from . import rks as _rks
+        except ImportError:
+            _rks = None
+        if _rks is not None:
+            _rks.patch(obj, BasisLayout.from_mol(obj.mol, alignment=1), dft_cutoff_fp32, dft_cutoff_fp64,
+                       numpy_boundary)
+
+    if hasattr(obj, "istype") and not obj.istype("DFRHF") and not obj.istype("DFRKS"):
+        def _mk(gen):
+            f = gen(basis_layout_jk, cutoff_fp32=jk_cutoff_fp32, cutoff_fp64=jk_cutoff_fp64)
+            return f
+        if hasattr(obj, "get_jk"):
+            get_jk = _jk.generate_jk_kernel(basis_layout_jk, cutoff_fp32=jk_cutoff_fp32, cutoff_fp64=jk_cutoff_fp64)
+            get_jk.return_numpy = numpy_boundary
+            obj.get_jk = get_jk
+            if hasattr(obj, "get_j"):
+                obj.get_j = lambda *a, **k: get_jk(*a, with_j=True, with_k=False, **k)[0]
+            if hasattr(obj, "get_k"):
+                obj.get_k = lambda *a, **k: get_jk(*a, with_j=False, with_k=True, **k)[1]
+        if _is(obj, "RHF") and not _is(obj, "RKS"):
+            obj.get_veff = MethodType(_jk.generate_get_veff(), obj)
+
+    obj._joltqc_applied = True
+    if not hasattr(obj, "_jqc_original_reset") and hasattr(obj, "reset"):
+        original_reset = obj.reset.__func__
+        obj._jqc_original_reset = original_reset
+        obj.reset = MethodType(create_reset_function(original_reset, config), obj)
+    if hasattr(obj, "as_scanner") and hasattr(obj.as_scanner, "__func__"):
+        obj.as_scanner = MethodType(create_scanner_wrapper(obj.as_scanner.__func__, config), obj)
+    return obj

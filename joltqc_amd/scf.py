@@ -1,0 +1,115 @@
+"""Minimal RHF driver with the attribute surface ``apply`` patches.
+
+Stand-in for ``pyscf.scf.RHF`` on images without PySCF (this one, and the GPU box): it owns the SCF
+loop, DIIS and the one-electron matrices handed to it, and calls ``self.get_veff`` /
+``self.get_jk`` exactly where PySCF does, so ``joltqc_amd.pyscf.apply(mf)`` patches it the same way
+it patches a PySCF object.  It computes no integrals itself: ``hcore`` and ``ovlp`` are supplied by
+the caller (PySCF's ``mf.get_hcore()`` / ``mf.get_ovlp()`` where PySCF exists; the test-suite's
+McMurchie-Davidson code otherwise).  Not part of the hot path.
+"""
+import numpy as np
+
+
+class RHF:
+    def __init__(self, mol, hcore=None, ovlp=None):
+        self.mol = mol
+        self._hcore = hcore
+        self._ovlp = ovlp
+        self.direct_scf = True
+        self.direct_scf_tol = 1e-13
+        self.conv_tol = 1e-10
+        self.max_cycle = 60
+        self.diis_space = 8
+        self.verbose = 0
+        self.mo_coeff = None
+        self.mo_energy = None
+        self.e_tot = None
+        self.converged = False
+        self.cycles = 0
+
+    # --- the PySCF surface apply() looks at -------------------------------------------------
+    def istype(self, name):
+        return name in ("RHF", "SCF")
+
+    def get_hcore(self, mol=None):
+        return self._hcore
+
+    def get_ovlp(self, mol=None):
+        return self._ovlp
+
+    def get_jk(self, mol=None, dm=None, hermi=1, **kw):
+        raise RuntimeError("no J/K engine attached: call joltqc_amd.pyscf.apply(mf) (or attach an oracle in tests)")
+
+    def get_veff(self, mol=None, dm=None, dm_last=None, vhf_last=None, hermi=1):
+        vj, vk = self.get_jk(mol, dm, hermi)
+        return vj - 0.5 * vk
+
+    def reset(self, mol=None):
+        if mol is not None:
+            self.mol = mol
+        return self
+
+    def make_rdm1(self, mo_coeff=None, nocc=None):
+        c = self.mo_coeff if mo_coeff is None else mo_coeff
+        nocc = self.mol.nelectron // 2 if nocc is None else nocc
+        return 2.0 * c[:, :nocc] @ c[:, :nocc].T
+
+    # --- SCF loop -----------------------------------------------------------------------------
+    @staticmethod
+    def _np(x):
+        return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+    def kernel(self, dm0=None):
+        S, h = np.asarray(self._ovlp), np.asarray(self._hcore)
+        s, U = np.linalg.eigh(S)
+        X = U[:, s > 1e-10] / np.sqrt(s[s > 1e-10])
+        nocc = self.mol.nelectron // 2
+        enuc = self.mol.energy_nuc()
+
+        def solve(F):
+            e, c = np.linalg.eigh(X.T @ F @ X)
+            return e, X @ c
+
+        if dm0 is None:
+            _, c = solve(h)
+            dm = 2.0 * c[:, :nocc] @ c[:, :nocc].T
+        else:
+            dm = np.asarray(dm0)
+        dm_last, vhf_last = None, None
+        errs, focks = [], []
+        e_last = 0.0
+        for it in range(self.max_cycle):
+            vhf = self._np(self.get_veff(self.mol, dm, dm_last=dm_last, vhf_last=vhf_last, hermi=1))
+            dm_last, vhf_last = dm, vhf
+            F = h + vhf
+            e_tot = 0.5 * float(np.einsum("ij,ji->", dm, h + F)) + enuc
+            err = X.T @ (F @ dm @ S - S @ dm @ F) @ X
+            focks.append(F)
+            errs.append(err)
+            focks, errs = focks[-self.diis_space:], errs[-self.diis_space:]
+            if len(errs) > 1:
+                n = len(errs)
+                B = -np.ones((n + 1, n + 1))
+                B[n, n] = 0
+                for a in range(n):
+                    for b in range(n):
+                        B[a, b] = float(np.vdot(errs[a], errs[b]))
+                rhs = np.zeros(n + 1)
+                rhs[n] = -1
+                try:
+                    w = np.linalg.solve(B, rhs)[:n]
+                    F = sum(wi * Fi for wi, Fi in zip(w, focks))
+                except np.linalg.LinAlgError:
+                    pass
+            self.mo_energy, self.mo_coeff = solve(F)
+            dm = 2.0 * self.mo_coeff[:, :nocc] @ self.mo_coeff[:, :nocc].T
+            self.cycles = it + 1
+            if abs(e_tot - e_last) < self.conv_tol and np.abs(err).max() < 1e-6:
+                self.converged = True
+                e_last = e_tot
+                break
+            e_last = e_tot
+        # final energy with the converged density
+        vhf = self._np(self.get_veff(self.mol, dm, dm_last=dm_last, vhf_last=vhf_last, hermi=1))
+        self.e_tot = 0.5 * float(np.einsum("ij,ji->", dm, 2 * h + vhf)) + enuc
+        return self.e_tot
