@@ -1,0 +1,87 @@
+"""Host logic of BasisLayout (modelled on the reference's tests/test_basis_layout.py)."""
+import numpy as np
+import pytest
+
+from conftest import H2O, benzene_atoms
+from joltqc_amd.constants import NPRIM_MAX
+from joltqc_amd.gto import mole
+from joltqc_amd.gto.c2s import cart2sph_l
+from joltqc_amd.pyscf.basis import BasisLayout, split_basis
+
+
+@pytest.fixture(scope="module")
+def mol():
+    return mole.Mole(atom=H2O, basis="def2-tzvpp")
+
+
+def test_split_respects_nprim_max(mol):
+    shells, parent = split_basis(mol)
+    assert max(len(s.exps) for s in shells) <= NPRIM_MAX
+    # O 6-primitive s -> two pieces, O 4-primitive p -> 3+1, sharing their parent
+    assert len(shells) == 25 and parent.max() + 1 == 23
+    assert np.all(np.diff(parent) >= 0)
+
+
+def test_groups_sorted_and_padded(mol):
+    for align in (1, 4):
+        lay = BasisLayout.from_mol(mol, alignment=align)
+        key = lay.group_key
+        order = [(int(l), -int(n)) for l, n in key]
+        assert order == sorted(order)
+        sizes = np.diff(lay.group_offset)
+        assert np.all(sizes % align == 0)
+        for g in range(lay.ngroups):
+            sl = slice(lay.group_offset[g], lay.group_offset[g + 1])
+            assert np.all(lay.angs[sl] == key[g, 0]) and np.all(lay.nprims[sl] == key[g, 1])
+        # pads have zero AO width and never change nao
+        w = np.diff(lay.ao_loc)
+        assert np.all(w[lay.pad_id] == 0)
+        assert lay.nao == 70
+        assert np.all(lay.packed[:, 3] == lay.ao_loc[:-1])
+
+
+def test_packed_rows(mol):
+    lay = BasisLayout.from_mol(mol)
+    for n in range(lay.nbasis):
+        np_ = int(lay.packed[n, 10])
+        assert np_ == lay.nprims[n] and int(lay.packed[n, 11]) == lay.angs[n]
+        assert np.all(lay.packed[n, 5:5 + 2 * np_:2] > 0)
+        assert np.all(lay.packed[n, 4 + 2 * np_:10:2] == 0)
+
+
+@pytest.mark.parametrize("cart", [False, True])
+def test_dm_roundtrip_dimensions_and_trace(cart):
+    mol = mole.Mole(atom=H2O, basis="def2-tzvpp", cart=cart)
+    lay = BasisLayout.from_mol(mol)
+    T = lay.transform_matrix()
+    assert T.shape == (lay.nao, mol.nao)
+    rng = np.random.default_rng(0)
+    d = rng.random((mol.nao, mol.nao))
+    d = d + d.T
+    v = rng.random((lay.nao, lay.nao))
+    # <D_int, V_int> == <D_mol, V_mol>: the two transforms are adjoint
+    lhs = np.sum((T @ d @ T.T) * v)
+    rhs = np.sum(d * (T.T @ v @ T))
+    assert abs(lhs - rhs) < 1e-9 * abs(lhs)
+
+
+def test_spatial_sort_is_a_permutation():
+    mol = mole.Mole(atom=benzene_atoms(), basis="def2-svp")
+    a = BasisLayout.from_mol(mol, spatial_sort=True)
+    b = BasisLayout.from_mol(mol, spatial_sort=False)
+    assert sorted(a.to_split_map.tolist()) == sorted(b.to_split_map.tolist())
+    assert np.array_equal(a.group_key, b.group_key) and np.array_equal(a.group_offset, b.group_offset)
+
+
+def test_cart2sph_known_values():
+    d = cart2sph_l(2)
+    assert abs(d[1, 0] - 1.092548430592079070) < 1e-15        # d_xy
+    assert abs(d[5, 2] - 0.630783130505040012) < 1e-15        # d_z2: zz
+    assert abs(d[0, 2] + 0.315391565252520002) < 1e-15
+    assert abs(d[0, 4] - 0.546274215296039535) < 1e-15        # d_x2-y2
+    f = cart2sph_l(3)
+    assert abs(f[4, 1] - 2.890611442640554055) < 1e-14        # f_xyz
+    assert abs(f[9, 3] - 0.746352665180230782) < 1e-14        # f_z3: zzz
+    for l in range(2, 5):
+        c = cart2sph_l(l)
+        assert c.shape == ((l + 1) * (l + 2) // 2, 2 * l + 1)

@@ -1,0 +1,149 @@
+"""GPU parity tests of the J/K path (through the C-ABI library) against the CPU oracle.
+Modelled on the reference's jqc/pyscf/tests/test_jk.py and test_scf.py."""
+import numpy as np
+import pytest
+
+from conftest import H2O, H2_BOHR, benzene_atoms
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(atom, basis, cart=False, unit="angstrom", cut64=1e-13, cut32=1e-13):
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import jk as jkmod
+    from joltqc_amd.pyscf.basis import BasisLayout
+    mol = mole.Mole(atom=atom, basis=basis, cart=cart, unit=unit)
+    lay = BasisLayout.from_mol(mol)
+    return mol, lay, jkmod.generate_jk_kernel(lay, cutoff_fp64=cut64, cutoff_fp32=cut32)
+
+
+def _dm(nao, seed=9, n=None):
+    np.random.seed(seed)
+    if n is None:
+        d = np.random.rand(nao, nao)
+        return d @ d.T
+    d = np.random.rand(n, nao, nao)
+    return np.einsum("nij,nkj->nik", d, d)
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def test_native_library_is_loaded():
+    from joltqc_amd.backend import lib as L
+    L.lib()
+    with open("/proc/self/maps") as f:
+        assert "libjqc_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("cart", [True, False])
+def test_jk_h2_tzvpp(cart):
+    # reference test_jk.py:62-103 (H2, def2-TZVPP, Bohr, seed 9, tol 1e-7); bar here 1e-9
+    from oracle import dense
+    mol, lay, get_jk = _setup(H2_BOHR, "def2-tzvpp", cart, unit="B")
+    dm = _dm(mol.nao)
+    vj, vk = get_jk(mol, dm, hermi=1)
+    rj, rk = dense.get_jk(lay, dm, hermi=1)
+    assert vj.shape == dm.shape and vk.shape == dm.shape
+    assert np.abs(_np(vj) - rj).max() < 1e-9
+    assert np.abs(_np(vk) - rk).max() < 1e-9
+
+
+def test_jk_multiple_dms_and_j_only_k_only():
+    from oracle import dense
+    mol, lay, get_jk = _setup(H2O, "def2-svp")
+    dm = _dm(mol.nao, n=3)
+    vj, vk = get_jk(mol, dm, hermi=1)
+    rj, rk = dense.get_jk(lay, dm, hermi=1)
+    assert vj.shape == dm.shape
+    assert np.abs(_np(vj) - rj).max() < 1e-9 and np.abs(_np(vk) - rk).max() < 1e-9
+    vj1, vk0 = get_jk(mol, dm[0], hermi=1, with_k=False)
+    vj0, vk1 = get_jk(mol, dm[0], hermi=1, with_j=False)
+    assert vk0 == 0 and vj0 == 0
+    assert np.abs(_np(vj1) - rj[0]).max() < 1e-9 and np.abs(_np(vk1) - rk[0]).max() < 1e-9
+
+
+def test_jk_hermi0_and_long_range():
+    from oracle import dense
+    mol, lay, get_jk = _setup(H2O, "def2-svp")
+    np.random.seed(3)
+    dm = np.random.rand(mol.nao, mol.nao)          # non-symmetric
+    vj, vk = get_jk(mol, dm, hermi=0)
+    rj, rk = dense.get_jk(lay, dm, hermi=0)
+    assert np.abs(_np(vj) - rj).max() < 1e-9 and np.abs(_np(vk) - rk).max() < 1e-9
+    dms = _dm(mol.nao)
+    for omega in (0.3, 0.5):                        # reference test_jk.py:171-216
+        vj, vk = get_jk(mol, dms, hermi=1, omega=omega)
+        rj, rk = dense.get_jk(lay, dms, hermi=1, omega=omega)
+        assert np.abs(_np(vj) - rj).max() < 1e-9 and np.abs(_np(vk) - rk).max() < 1e-9
+    with pytest.raises(AssertionError):
+        get_jk(mol, dms, hermi=1, omega=-0.1)
+
+
+def test_jk_fp32_and_mixed_precision():
+    # reference test_jk.py:105-121 (pure fp32 < 1e-3) and :218-248 (mixed 1e-13/1e-7 < 1e-7)
+    from oracle import dense
+    mol, lay, _ = _setup(H2O, "def2-svp")
+    dm = _dm(mol.nao)
+    rj, rk = dense.get_jk(lay, dm, hermi=1)
+    _, _, jk32 = _setup(H2O, "def2-svp", cut64=1e100, cut32=1e-13)
+    vj, vk = jk32(mol, dm, hermi=1)
+    n64, n32, _ = jk32.quartet_counts()
+    assert n64 == 0 and n32 > 0
+    assert np.abs(_np(vj) - rj).max() < 1e-3 and np.abs(_np(vk) - rk).max() < 1e-3
+    _, _, jkmix = _setup(H2O, "def2-svp", cut64=1e-7, cut32=1e-13)
+    vj, vk = jkmix(mol, dm, hermi=1)
+    assert np.abs(_np(vj) - rj).max() < 1e-7 and np.abs(_np(vk) - rk).max() < 1e-7
+
+
+def test_jk_screening_far_apart_atoms():
+    # reference test_jk.py:250-276: 100 Bohr apart -> inter-atomic quartets are screened out
+    from oracle import dense
+    mol, lay, get_jk = _setup("H 0 0 0; H 0 0 100", "def2-tzvpp", unit="B")
+    dm = _dm(mol.nao)
+    vj, vk = get_jk(mol, dm, hermi=1)
+    rj, rk = dense.get_jk(lay, dm, hermi=1)
+    n64, _, _ = get_jk.quartet_counts()
+    assert n64 < len(dense.canonical_quartets(lay))
+    assert np.abs(_np(vj) - rj).max() < 1e-9 and np.abs(_np(vk) - rk).max() < 1e-9
+
+
+@pytest.mark.skip(reason="(gg|gg) needs the tiled kernel; 1q1t would need 400 KB scratch per lane")
+def test_g_functions_class():
+    # LMAX = 4 path (reference test_scf.py:90-108 uses def2-QZVPP H2); inline basis with one g shell per atom
+    from oracle import dense
+    basis = {"H": [[0, [1.2, 1.0]], [4, [1.1, 1.0]]]}
+    mol, lay, get_jk = _setup("H 0 0 0; H 0 0 1.4", basis, unit="B")
+    dm = _dm(mol.nao)
+    vj, vk = get_jk(mol, dm, hermi=1)
+    rj, rk = dense.get_jk(lay, dm, hermi=1)
+    assert np.abs(_np(vj) - rj).max() < 1e-9 and np.abs(_np(vk) - rk).max() < 1e-9
+
+
+def test_rhf_energy_h2o_tzvpp_through_apply(kats):
+    """BASELINE config 1 on the GPU path: apply(mf) on the stand-in RHF object."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from joltqc_amd.scf import RHF
+    from oracle import dense
+    k = kats["h2o_def2tzvpp"]
+    mol = mole.Mole(atom=k["atom"], basis="def2-tzvpp")
+    S, T, V = dense.int1e_mol(BasisLayout.from_mol(mol), mol)
+    mf = jp.apply(RHF(mol, T + V, S))
+    assert mf._joltqc_applied
+    e = mf.kernel()
+    assert mf.converged
+    assert abs(e - k["e_rhf_sph"]) < 1e-8, e - k["e_rhf_sph"]
+
+
+def test_benzene_svp_parity_full_size():
+    from oracle import dense
+    mol, lay, get_jk = _setup(benzene_atoms(), "def2-svp")
+    dm = _dm(mol.nao)
+    vj, vk = get_jk(mol, dm, hermi=1)
+    rj, rk = dense.get_jk(lay, dm, hermi=1)
+    scale = max(np.abs(rj).max(), np.abs(rk).max())
+    assert np.abs(_np(vj) - rj).max() < 1e-11 * scale
+    assert np.abs(_np(vk) - rk).max() < 1e-11 * scale
