@@ -29,6 +29,8 @@ extern "C" {
 
 const char* jqc_last_error(void);
 const char* jqc_version(void);
+/* tag (hash of the kernel sources) embedded in every cached code-object name; valid after jqc_set_kernel_dirs */
+const char* jqc_source_tag(void);
 
 /* Runtime set-up.  src_dir holds the kernel sources (joltqc_amd/csrc/kernels), cache_dir receives
  * the gfx950 code objects (one .hsaco per class/variant; replaces CuPy's cubin cache, examples/04). */
@@ -49,6 +51,20 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
 int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, double* vj_d, double* vk_d,
                   double omega, const void* quartets_d, const uint32_t* ntasks_d, int64_t ntasks_max,
                   int qstride, int n_dm, void* stream);
+
+/* Launch of a tiled J/K kernel (JQC_ALGO_TILE).  No quartet queue: one workgroup per (bra tile pair, ket tile
+ * pair); screening (same predicate as jqc_screen_jk_tasks) happens inside the workgroup.
+ *   tasks_d     int32[ntasks][8] = {ij0, nij, kl0, nkl, 0, blk0, cnt, 0}: rectangle of tile-pair lists, nij*nkl blocks
+ *   tpair_sh_d  uint32[...] = first shell of tile i <<16 | first shell of tile j; tpair_q_d = max log-Schwarz of the pair
+ *   q_cond_d, log_dm_d  float[nbas*nbas];  processes quartets with cut_lo < q_ij+q_kl+d_large <= cut_hi
+ *   counter_d   optional uint64[]: the number of quartets evaluated by a workgroup is added to counter_d[cnt]
+ *               (per-class dispatch counters = the "ERI quartets/s" metric, reference jk.py:288-330)
+ * Tile widths are fixed per angular momentum: 4 shells for l<=2, 2 for l=3, 1 for l=4; every (l,nprim) group of
+ * the shell table must be padded to that multiple (BasisLayout.from_mol(alignment=tile_width)). */
+int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_d, double* vj_d, double* vk_d,
+                       double omega, const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* tpair_sh_d,
+                       const float* tpair_q_d, const float* q_cond_d, const float* log_dm_d, int nbas, float cut_lo,
+                       float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, void* stream);
 
 /* Screening + queue generation (replaces screen_jk_tasks, jqc/backend/jk/screen_jk_tasks.cu:75-340).
  * One launch handles a whole chunk of "screen tasks"; task t covers the rectangle

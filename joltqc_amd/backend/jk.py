@@ -29,9 +29,12 @@ def class_key(ang):
 
 def select_algo(ang, fp32=False):
     t = _table().get("fp32" if fp32 else "fp64", {})
+    forced = os.environ.get("JQC_JK_ALGO")
+    if forced:
+        return _lib.ALGO_1Q1T if forced.lower() in ("0", "1q1t") else _lib.ALGO_TILE
     v = t.get(class_key(ang))
     if v is None:
-        return _lib.ALGO_1Q1T
+        return _lib.ALGO_TILE
     return int(v)
 
 

@@ -51,10 +51,13 @@ def lib():
         vp, i32, i64, f32, f64 = c.c_void_p, c.c_int, c.c_int64, c.c_float, c.c_double
         L.jqc_last_error.restype = c.c_char_p
         L.jqc_version.restype = c.c_char_p
+        L.jqc_source_tag.restype = c.c_char_p
         L.jqc_set_kernel_dirs.argtypes = [c.c_char_p, c.c_char_p]
         L.jqc_set_rys_tables.argtypes = [vp, c.c_size_t]
         L.jqc_gen_jk_kernel.argtypes = [i32] * 10
         L.jqc_jk_launch.argtypes = [i32, i32, vp, vp, vp, vp, f64, vp, vp, i64, i32, i32, vp]
+        L.jqc_jk_tile_launch.argtypes = [i32, i32, vp, vp, vp, vp, f64, vp, i32, i32, vp, vp, vp, vp, i32, f32, f32, f32,
+                                         i32, vp, vp]
         L.jqc_screen_jk_tasks.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp]
         L.jqc_shell_block_max.argtypes = [vp, i32, i32, vp, i32, vp, vp]
         L.jqc_schwarz.argtypes = [i32, i32, vp, vp, i32, f64, vp, vp]
@@ -62,6 +65,17 @@ def lib():
         L.jqc_set_kernel_dirs(KERNEL_SRC.encode(), KERNEL_CACHE.encode())
         _lib = L
         return _lib
+
+
+def purge_stale_cache():
+    """Remove cached code objects that were built from other versions of the kernel sources."""
+    tag = lib().jqc_source_tag().decode()
+    n = 0
+    for f in os.listdir(KERNEL_CACHE):
+        if f.endswith(".hsaco") and not f.endswith("_" + tag + ".hsaco"):
+            os.remove(os.path.join(KERNEL_CACHE, f))
+            n += 1
+    return n
 
 
 def check(rc):

@@ -9,4 +9,11 @@ TILE = 4            # group alignment asked for by apply() for the JK layout (ke
 SLOT_NPRIM = 10
 SLOT_ANG = 11
 
-__all__ = ["LMAX", "NPRIM_MAX", "BASIS_STRIDE", "TILE", "SLOT_NPRIM", "SLOT_ANG"]
+
+
+def tile_width(l: int) -> int:
+    """Shells per tile edge of the tiled J/K kernels (joltqc_amd/csrc/kernels/jk_tile.hip: ts_of)."""
+    return 4 if l <= 2 else (2 if l == 3 else 1)
+
+
+__all__ = ["LMAX", "NPRIM_MAX", "BASIS_STRIDE", "TILE", "SLOT_NPRIM", "SLOT_ANG", "tile_width"]

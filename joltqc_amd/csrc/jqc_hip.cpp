@@ -28,6 +28,7 @@ namespace {
 thread_local std::string g_err;
 std::mutex g_mu;
 std::string g_src_dir, g_cache_dir;
+std::string g_src_tag = "nosrc";   // FNV-1a of every kernel source: stale code objects are never reused
 
 int fail(int code, const char* fmt, ...)
 {
@@ -232,6 +233,7 @@ extern "C" {
 
 const char* jqc_last_error(void) { return g_err.c_str(); }
 const char* jqc_version(void) { return "joltqc_amd 0.1 (gfx950)"; }
+const char* jqc_source_tag(void) { return g_src_tag.c_str(); }
 
 int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
 {
@@ -239,6 +241,14 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
     g_src_dir = src_dir ? src_dir : "";
     g_cache_dir = cache_dir ? cache_dir : "";
     if (!g_cache_dir.empty()) mkdir(g_cache_dir.c_str(), 0755);
+    unsigned long long h = 1469598103934665603ull;
+    for (const char* f : {"jk_common.h", "jk_axis.h", "jk_1q1t.hip", "jk_tile.hip", "schwarz.hip"}) {
+        const std::string txt = read_file(g_src_dir + "/" + f);
+        for (unsigned char ch : txt) { h ^= ch; h *= 1099511628211ull; }
+    }
+    char tag[32];
+    snprintf(tag, sizeof tag, "%010llx", h & 0xffffffffffull);
+    g_src_tag = tag;
     return 0;
 }
 
@@ -271,7 +281,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     if (it != g_by_key.end() && (compile_only || g_kernels[it->second].fn)) return it->second;
     const char* src = algo == JQC_ALGO_TILE ? "jk_tile.hip" : "jk_1q1t.hip";
     const char* entry = algo == JQC_ALGO_TILE ? "jk_tile" : "jk_1q1t";
-    const std::string out = g_cache_dir + "/" + key + ".hsaco";
+    const std::string out = g_cache_dir + "/" + key + "_" + g_src_tag + ".hsaco";
     if (!file_exists(out)) {
         std::vector<std::string> d = {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
                                       "-DLK=" + std::to_string(lk), "-DLL=" + std::to_string(ll),
@@ -323,6 +333,28 @@ int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, do
     return 0;
 }
 
+int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_d, double* vj_d, double* vk_d,
+                       double omega, const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* tpair_sh_d,
+                       const float* tpair_q_d, const float* q_cond_d, const float* log_dm_d, int nbas, float cut_lo,
+                       float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, void* stream)
+{
+    if (handle < 0 || handle >= (int)g_kernels.size() || !g_kernels[handle].fn)
+        return fail(-1, "invalid kernel handle %d", handle);
+    if (g_kernels[handle].algo != JQC_ALGO_TILE) return fail(-1, "handle %d is not a tile kernel", handle);
+    if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
+    if (ntasks <= 0 || nblocks <= 0) return 0;
+    const Kernel& k = g_kernels[handle];
+    const int n = k.nroots;
+    float omega_f = (float)omega;
+    const void* cheb = k.fp32 ? (const void*)rys_cheb32(n) : (const void*)rys_cheb64(n);
+    const void* large = k.fp32 ? (const void*)rys_large32(n) : (const void*)rys_large64(n);
+    void* args[] = {&nao, &basis_d, &dm_d, &vj_d, &vk_d, k.fp32 ? (void*)&omega_f : (void*)&omega, &tasks_d, &ntasks,
+                    &tpair_sh_d, &tpair_q_d, &q_cond_d, &log_dm_d, &nbas, &cut_lo, &cut_hi, &log_max_dm, &n_dm,
+                    &cheb, &large, &counter_d};
+    HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)nblocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+    return 0;
+}
+
 int jqc_screen_jk_tasks(const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* pair_sh_d,
                         const float* pair_q_d, const float* log_dm_d, int nbas, int do_j, int do_k,
                         float log_cutoff_fp32, float log_cutoff_fp64, float log_max_dm, void* queue_d,
@@ -359,7 +391,7 @@ int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d
         snprintf(key, sizeof key, "schwarz_%d%d_lr%d", li, lj, lr);
         auto it = g_by_key.find(key);
         if (it == g_by_key.end()) {
-            const std::string out = g_cache_dir + "/" + key + ".hsaco";
+            const std::string out = g_cache_dir + "/" + key + "_" + g_src_tag + ".hsaco";
             if (!file_exists(out)) {
                 int rc = compile_to("schwarz.hip", {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
                                                     "-DRYS_LR=" + std::to_string(lr)}, out);

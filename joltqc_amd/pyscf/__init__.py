@@ -85,11 +85,11 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
 
     from . import jk as _jk
     from .basis import BasisLayout
-    from ..constants import TILE
+    from ..constants import tile_width
 
-    # the reference builds two layouts (alignment 1 for DFT, TILE for JK, __init__.py:188-189); the
-    # pair-list screening of this build needs no tile padding, the argument is kept for API parity
-    basis_layout_jk = BasisLayout.from_mol(obj.mol, alignment=1)
+    # the reference builds two layouts (alignment 1 for DFT, TILE=4 for JK, __init__.py:188-189); here the
+    # JK layout pads every (l, nprim) group to the tile width of the tiled kernels (4/4/4/2/1 for s..g)
+    basis_layout_jk = BasisLayout.from_mol(obj.mol, alignment=tile_width)
     obj._jqc_basis_layout = basis_layout_jk
     numpy_boundary = not is_device_obj
 

@@ -89,7 +89,8 @@ def sort_group_basis(shells, alignment=1, spatial_sort=True):
                         code |= ((int(q[d]) >> b) & 1) << (3 * b + d)
                 return (code, i)
             idxs = sorted(idxs, key=morton)
-        npad = (-len(idxs)) % alignment
+        align = alignment(k[0]) if callable(alignment) else int(alignment)
+        npad = (-len(idxs)) % align
         order += idxs + [idxs[0]] * npad
         pad += [False] * len(idxs) + [True] * npad
         gkey.append(k)
@@ -118,7 +119,7 @@ class BasisLayout:
 
     # ------------------------------------------------------------------ construction
     @classmethod
-    def from_mol(cls, mol, alignment: int = 1, dtype=np.float64, spatial_sort: bool = True) -> "BasisLayout":
+    def from_mol(cls, mol, alignment=1, dtype=np.float64, spatial_sort: bool = True) -> "BasisLayout":
         shells, parent = split_basis(mol)
         assert all(s.l <= LMAX for s in shells), f"angular momentum above {LMAX} is not supported"
         order, pad, gkey, goff = sort_group_basis(shells, alignment, spatial_sort)

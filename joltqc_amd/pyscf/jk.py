@@ -29,6 +29,7 @@ __all__ = ["generate_jk_kernel", "generate_get_j", "generate_get_k", "generate_g
 PAIR_CUTOFF = 1e-13          # reference jk.py:48
 QUEUE_DEPTH = 1 << 26        # quartets per chunk (8 B each -> 512 MiB); reference uses 2^28 (jk_tasks.py:30)
 STRIPS_PER_LIST = 64         # host-side trimming granularity of the sorted pair lists
+N_STREAMS = int(__import__('os').environ.get('JQC_STREAMS', '8'))                # class kernels are independent (atomic accumulation): spread them over HIP streams
 
 
 def generate_get_j(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
@@ -130,7 +131,8 @@ def _class_id(ang):
     return ((ang[0] * 5 + ang[1]) * 5 + ang[2]) * 5 + ang[3]
 
 
-def build_screen_plan(layout, pt: "_PairTables", log_cut: float, log_max_dm: float, queue_depth: int):
+def build_screen_plan(layout, pt: "_PairTables", log_cut: float, log_max_dm: float, queue_depth: int, want=None,
+                      shard=None):
     """Host-side plan of one get_jk call: list of chunks, each with its screen tasks, the per-class
     queue regions and upper bounds.  Everything is derived from the sorted Schwarz lists; no
     device work, no synchronisation."""
@@ -139,6 +141,8 @@ def build_screen_plan(layout, pt: "_PairTables", log_cut: float, log_max_dm: flo
     pair_cut = math.log(PAIR_CUTOFF) - log_max_dm          # reference jk.py:184-186
     nkeep = {k: int(np.searchsorted(-q, -pair_cut, side="left")) for k, q in pt.q_host.items()}
     raw = []   # (cls, ang, ij0, nij, kl0, nkl)
+    strip_no = 0
+    rank, world = shard if shard is not None else (0, 1)
     for gi in range(ng):
         for gj in range(gi + 1):
             nij_all = nkeep.get((gi, gj), 0)
@@ -152,6 +156,8 @@ def build_screen_plan(layout, pt: "_PairTables", log_cut: float, log_max_dm: flo
                         continue
                     qkl = pt.q_host[gk, gl]
                     ang = (int(gkey[gi, 0]), int(gkey[gj, 0]), int(gkey[gk, 0]), int(gkey[gl, 0]))
+                    if want is not None and not want(ang):
+                        continue
                     strip = max(16, -(-nij_all // STRIPS_PER_LIST))
                     strip = (strip + 15) // 16 * 16
                     for s0 in range(0, nij_all, strip):
@@ -161,6 +167,9 @@ def build_screen_plan(layout, pt: "_PairTables", log_cut: float, log_max_dm: flo
                         n_kl = min(nkl_all, int(np.searchsorted(-qkl, -thr, side="left")))
                         if n_kl <= 0:
                             break
+                        strip_no += 1
+                        if strip_no % world != rank:
+                            continue
                         raw.append((_class_id(ang), ang, pt.offset[gi, gj] + s0, n_ij, pt.offset[gk, gl], n_kl))
     # split oversize tasks, then pack chunks
     tasks = []
@@ -212,7 +221,105 @@ def build_screen_plan(layout, pt: "_PairTables", log_cut: float, log_max_dm: flo
     return plans
 
 
-def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
+class _TileTables:
+    """Per group pair (gi >= gj): list of shell-tile pairs sorted by their largest Schwarz bound.
+    Tile = ``tile_width(l)`` consecutive shells of one (l, nprim) group (groups are padded to that
+    multiple); plays the role of ``make_tile_pairs`` (reference jk.py:385-431)."""
+
+    def __init__(self, layout, omega):
+        import torch
+        from ..constants import tile_width
+        dev = _lib.require_gpu()
+        self.q_dev = layout.q_matrix(omega)
+        q_host = self.q_dev.cpu().numpy()
+        goff, gkey = layout.group_offset, layout.group_key
+        self.offset: Dict[Tuple[int, int], int] = {}
+        self.q_host: Dict[Tuple[int, int], np.ndarray] = {}
+        sh_all, q_all, off = [], [], 0
+        for gi in range(layout.ngroups):
+            wi = tile_width(int(gkey[gi, 0]))
+            assert (goff[gi + 1] - goff[gi]) % wi == 0, "layout groups must be padded to the tile width"
+            ti = np.arange(goff[gi], goff[gi + 1], wi)
+            for gj in range(gi + 1):
+                wj = tile_width(int(gkey[gj, 0]))
+                tj = np.arange(goff[gj], goff[gj + 1], wj)
+                blk = q_host[goff[gi]:goff[gi + 1], goff[gj]:goff[gj + 1]]
+                qt = blk.reshape(len(ti), wi, len(tj), wj).max(axis=(1, 3))
+                ii, jj = np.meshgrid(ti, tj, indexing="ij")
+                m = qt > -80.0
+                if gi == gj:
+                    m &= ii >= jj
+                if not m.any():
+                    continue
+                ii, jj, qq = ii[m], jj[m], qt[m]
+                order = np.argsort(-qq, kind="stable")
+                sh = ((ii[order].astype(np.uint32) << np.uint32(16)) | jj[order].astype(np.uint32)).astype(np.uint32)
+                self.offset[gi, gj] = off
+                self.q_host[gi, gj] = qq[order].astype(np.float32)
+                sh_all.append(sh)
+                q_all.append(self.q_host[gi, gj])
+                off += sh.size
+        if off:
+            self.sh = torch.from_numpy(np.concatenate(sh_all).view(np.int32)).to(dev)
+            self.q = torch.from_numpy(np.concatenate(q_all)).to(dev)
+        else:
+            self.sh = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.q = torch.zeros(1, dtype=torch.float32, device=dev)
+
+
+def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float, want, shard=None):
+    """Task tables of the tiled kernels for one call: {ang: int32[ntasks, 8]} with rows
+    (ij0, nij, kl0, nkl, 0, blk0, 0, 0); one workgroup per (tile pair ij, tile pair kl)."""
+    gkey = layout.group_key
+    ng = layout.ngroups
+    pair_cut = math.log(PAIR_CUTOFF) - log_max_dm
+    nkeep = {k: int(np.searchsorted(-q, -pair_cut, side="left")) for k, q in tt.q_host.items()}
+    per_class: Dict[Tuple[int, int, int, int], list] = {}
+    strip_no = 0
+    rank, world = shard if shard is not None else (0, 1)
+    for gi in range(ng):
+        for gj in range(gi + 1):
+            nij_all = nkeep.get((gi, gj), 0)
+            if nij_all == 0:
+                continue
+            qij = tt.q_host[gi, gj]
+            for gk in range(gi + 1):
+                for gl in range(gk + 1):
+                    nkl_all = nkeep.get((gk, gl), 0)
+                    if nkl_all == 0:
+                        continue
+                    ang = (int(gkey[gi, 0]), int(gkey[gj, 0]), int(gkey[gk, 0]), int(gkey[gl, 0]))
+                    if not want(ang):
+                        continue
+                    qkl = tt.q_host[gk, gl]
+                    rows = per_class.setdefault(ang, [])
+                    strip = max(1, -(-nij_all // STRIPS_PER_LIST))
+                    for s0 in range(0, nij_all, strip):
+                        n_ij = min(strip, nij_all - s0)
+                        thr = log_cut - log_max_dm - float(qij[s0])
+                        n_kl = min(nkl_all, int(np.searchsorted(-qkl, -thr, side="left")))
+                        if n_kl <= 0:
+                            break
+                        strip_no += 1
+                        if strip_no % world != rank:
+                            continue                      # another rank's share of the quartet work
+                        rows.append((tt.offset[gi, gj] + s0, n_ij, tt.offset[gk, gl], n_kl,
+                                     (int(gkey[gi, 1]), int(gkey[gj, 1]), int(gkey[gk, 1]), int(gkey[gl, 1]))))
+    plans = {}
+    for ang, rows in per_class.items():
+        tab = np.zeros((len(rows), 8), dtype=np.int32)
+        blk = 0
+        for n, (ij0, nij, kl0, nkl, _) in enumerate(rows):
+            tab[n, :6] = (ij0, nij, kl0, nkl, 0, blk)
+            blk += nij * nkl
+            assert blk < 2 ** 31
+        plans[ang] = (tab, blk, [r[4] for r in rows])
+    return plans
+
+
+def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard=None):
+    """``shard=(rank, world_size)``: this process evaluates its share of the quartet work and the raw
+    Fock contributions are summed over ranks with ONE all-reduce (RCCL) before the epilogue."""
     import torch
     log_cutoff_fp64 = float(np.float32(math.log(cutoff_fp64)))
     log_cutoff_fp32 = float(np.float32(math.log(cutoff_fp32)))
@@ -220,7 +327,11 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
     layout = basis_layout
     nbas = layout.nbasis
     nao = layout.nao
-    state = {"pairs": {}, "queue": None, "stats": {}}
+    from ..constants import tile_width
+    # the tiled kernels need every (l, nprim) group padded to its tile width
+    tiled_layout = all((layout.group_offset[g + 1] - layout.group_offset[g]) % tile_width(int(layout.group_key[g, 0])) == 0
+                       for g in range(layout.ngroups))
+    state = {"pairs": {}, "tiles": {}, "queue": None, "stats": {}, "probe": None, "plan_cache": {}, "streams": None}
 
     def get_jk(mol_ref=None, dm=None, hermi=0, vhfopt=None, with_j=True, with_k=True, omega=None, verbose=None):
         """Compute J, K; compatible with ``pyscf.scf.hf.get_jk`` / the reference closure (jk.py:109-118).
@@ -251,26 +362,109 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
         # d_large is floored at -36.8 inside the predicate (screen_jk_tasks.cu:241), so is every bound here
         log_max_dm = max(float(log_dm_cond.max().item()), -36.8)
 
-        if om not in state["pairs"]:
-            state["pairs"][om] = _PairTables(layout, om)
-        pt = state["pairs"][om]
-
         if hermi == 0:
             dms = torch.cat([dms, dms.transpose(1, 2)], dim=0).contiguous()   # jk.py:189-191
         n_dm = dms.shape[0]
         dms_fp32 = dms.float().contiguous() if mixed else None
-        vj = torch.zeros_like(dms) if with_j else None
-        vk = torch.zeros_like(dms) if with_k else None
-
-        plans = build_screen_plan(layout, pt, log_cutoff_fp32, log_max_dm, QUEUE_DEPTH)
-        qsize = max((p["total"] for p in plans), default=0)
-        if state["queue"] is None or state["queue"].numel() < qsize * 4:
-            state["queue"] = torch.empty(max(qsize, 1) * 4, dtype=torch.int16, device=dev)
-        queue = state["queue"]
+        fock = torch.zeros((int(with_j) + int(with_k),) + tuple(dms.shape), dtype=torch.float64, device=dev)
+        vj = fock[0] if with_j else None
+        vk = fock[-1] if with_k else None
+        vj_p = vj.data_ptr() if with_j else None
+        vk_p = vk.data_ptr() if with_k else None
         b64 = layout.basis_data_fp64["packed"]
         b32 = layout.basis_data_fp32["packed"] if mixed else None
+        is_tile = lambda ang: _router.select_algo(ang) == _lib.ALGO_TILE
         n_launch = 0
         counter_bufs = []
+        tile_counts = None
+        INF = 3.0e38
+
+        # ---------------- tiled kernels: no queue, one launch per angular class, classes spread over streams
+        if tiled_layout:
+            if om not in state["tiles"]:
+                state["tiles"][om] = _TileTables(layout, om)
+            tt = state["tiles"][om]
+            # the plan only depends on the density through log_max_dm: bucket it (upwards = looser, safe)
+            bucket = math.ceil(log_max_dm * 2.0) / 2.0
+            pkey = (om, bucket, shard)
+            if pkey not in state["plan_cache"]:
+                tplans = build_tile_plan(layout, tt, log_cutoff_fp32, bucket, is_tile, shard)
+                entry = None
+                if tplans:
+                    from ..roofline import quartet_flops
+                    cost = {a: sum(int(r[1]) * int(r[3]) for r in tplans[a][0]) * quartet_flops(a) for a in tplans}
+                    order = sorted(tplans, key=lambda a: -cost[a])              # longest first over the streams
+                    tabs = np.concatenate([tplans[a][0] for a in order])
+                    tabs[:, 6] = np.arange(tabs.shape[0])                       # counter slot of every task row
+                    entry = {"order": order, "tabs_d": torch.from_numpy(tabs).to(dev), "nrows": tabs.shape[0],
+                             "plans": tplans, "row_meta": [(a, npr) for a in order for npr in tplans[a][2]]}
+                if len(state["plan_cache"]) > 64:
+                    state["plan_cache"].clear()
+                state["plan_cache"][pkey] = entry
+            entry = state["plan_cache"][pkey]
+            if entry is not None:
+                order, tabs_d, tplans = entry["order"], entry["tabs_d"], entry["plans"]
+                tile_counts = torch.zeros((2, entry["nrows"]), dtype=torch.int64, device=dev)
+                if state["streams"] is None:
+                    state["streams"] = [torch.cuda.Stream(device=dev) for _ in range(N_STREAMS)]
+                side = state["streams"]
+                cur = torch.cuda.current_stream()
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                for st_ in side:
+                    st_.wait_event(ev)
+                row = 0
+                for n, ang in enumerate(order):
+                    tab, nblk, _ = tplans[ang]
+                    sid = side[n % len(side)]
+                    sp = sid.cuda_stream
+                    h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=_lib.ALGO_TILE)
+                    probing = state["probe"] is not None and (state["probe"] == "all" or tuple(state["probe"]) == tuple(ang))
+                    if probing:
+                        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ev0.record(sid)
+                    _lib.check(L.jqc_jk_tile_launch(h64, nao, b64.data_ptr(), dms.data_ptr(), vj_p, vk_p, om,
+                                                    tabs_d.data_ptr() + row * 32, tab.shape[0], nblk, tt.sh.data_ptr(),
+                                                    tt.q.data_ptr(), tt.q_dev.data_ptr(), log_dm_cond.data_ptr(), nbas,
+                                                    log_cutoff_fp64 if mixed else log_cutoff_fp32, INF, log_max_dm, n_dm,
+                                                    tile_counts[0].data_ptr(), sp))
+                    if probing:
+                        ev1.record(sid)
+                        state["stats"].setdefault("probe_events", []).append((ev0, ev1))
+                        state["stats"].setdefault("probe_classes", []).append(tuple(ang))
+                    n_launch += 1
+                    if mixed:
+                        h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True,
+                                                    algo=_lib.ALGO_TILE)
+                        _lib.check(L.jqc_jk_tile_launch(h32, nao, b32.data_ptr(), dms_fp32.data_ptr(), vj_p, vk_p, om,
+                                                        tabs_d.data_ptr() + row * 32, tab.shape[0], nblk,
+                                                        tt.sh.data_ptr(), tt.q.data_ptr(), tt.q_dev.data_ptr(),
+                                                        log_dm_cond.data_ptr(), nbas, log_cutoff_fp32, log_cutoff_fp64,
+                                                        log_max_dm, n_dm, tile_counts[1].data_ptr(), sp))
+                        n_launch += 1
+                    row += tab.shape[0]
+                for st_ in side:
+                    e2 = torch.cuda.Event()
+                    e2.record(st_)
+                    cur.wait_event(e2)
+                state["stats"]["tile_rows"] = entry["row_meta"]
+
+        # ---------------- queue path (one quartet per lane) for the classes routed to it
+        want_q = (lambda ang: not is_tile(ang)) if tiled_layout else None
+        need_queue = (not tiled_layout) or any(
+            not is_tile((int(a), int(b), int(c), int(d)))
+            for a in set(layout.angs) for b in set(layout.angs) for c in set(layout.angs) for d in set(layout.angs)
+            if a >= b and a >= c and c >= d)
+        plans = []
+        if need_queue:
+            if om not in state["pairs"]:
+                state["pairs"][om] = _PairTables(layout, om)
+            pt = state["pairs"][om]
+            plans = build_screen_plan(layout, pt, log_cutoff_fp32, log_max_dm, QUEUE_DEPTH, want_q, shard)
+        qsize = max((p["total"] for p in plans), default=0)
+        if plans and (state["queue"] is None or state["queue"].numel() < qsize * 4):
+            state["queue"] = torch.empty(max(qsize, 1) * 4, dtype=torch.int16, device=dev)
+        queue = state["queue"]
         for p in plans:
             ncls = len(p["classes"])
             tasks_d = torch.from_numpy(p["tasks"]).to(dev)
@@ -284,19 +478,24 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
             n_launch += 1
             for n, ang in enumerate(p["classes"]):
                 beg, end = int(p["region"][n, 0]), int(p["region"][n, 1])
-                h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False)
-                _lib.check(L.jqc_jk_launch(h64, nao, b64.data_ptr(), dms.data_ptr(),
-                                           vj.data_ptr() if with_j else None, vk.data_ptr() if with_k else None, om,
+                h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=_lib.ALGO_1Q1T)
+                _lib.check(L.jqc_jk_launch(h64, nao, b64.data_ptr(), dms.data_ptr(), vj_p, vk_p, om,
                                            queue.data_ptr() + beg * 8, counters.data_ptr() + (2 * n) * 4,
                                            end - beg, 1, n_dm, stream))
                 n_launch += 1
                 if mixed:
-                    h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True)
-                    _lib.check(L.jqc_jk_launch(h32, nao, b32.data_ptr(), dms_fp32.data_ptr(),
-                                               vj.data_ptr() if with_j else None, vk.data_ptr() if with_k else None,
+                    h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True,
+                                                algo=_lib.ALGO_1Q1T)
+                    _lib.check(L.jqc_jk_launch(h32, nao, b32.data_ptr(), dms_fp32.data_ptr(), vj_p, vk_p,
                                                om, queue.data_ptr() + (end - 1) * 8,
                                                counters.data_ptr() + (2 * n + 1) * 4, end - beg, -1, n_dm, stream))
                     n_launch += 1
+
+        if shard is not None and shard[1] > 1:
+            import torch.distributed as dist
+            dist.all_reduce(fock)                 # the one collective of the path: sum of raw J/K over ranks
+            vj = fock[0] if with_j else None
+            vk = fock[-1] if with_k else None
 
         # epilogue (reference jk.py:350-370)
         if with_j:
@@ -323,6 +522,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
         st["launches"] = n_launch
         st["chunks"] = len(plans)
         st["counter_bufs"] = counter_bufs          # read lazily by quartet_counts()
+        st["tile_counts"] = tile_counts
         st["host_seconds"] = time.perf_counter() - t_start
         if isinstance(dm_in, np.ndarray) and getattr(get_jk, "return_numpy", False):
             vj = vj.cpu().numpy() if with_j else 0
@@ -330,19 +530,35 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
         return vj, vk
 
     def quartet_counts():
-        """(n_fp64, n_fp32) quartets dispatched by the last call (synchronises)."""
+        """(n_fp64, n_fp32, {(ang, nprim): [n64, n32]}) quartets dispatched by the last call (synchronises)."""
         n64 = n32 = 0
         per_class = {}
+        tc = state["stats"].get("tile_counts")
+        if tc is not None:
+            c = tc.cpu().numpy()
+            n64 += int(c[0].sum())
+            n32 += int(c[1].sum())
+            for n, key in enumerate(state["stats"]["tile_rows"]):
+                a = per_class.setdefault(key, [0, 0])
+                a[0] += int(c[0, n])
+                a[1] += int(c[1, n])
         for counters, p in state["stats"].get("counter_bufs", []):
             c = counters.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
             n64 += int(c[:, 0].sum())
             n32 += int(c[:, 1].sum())
             for n, ang in enumerate(p["classes"]):
-                a = per_class.setdefault(tuple(ang), [0, 0])
+                a = per_class.setdefault((tuple(ang), None), [0, 0])
                 a[0] += int(c[n, 0])
                 a[1] += int(c[n, 1])
         return n64, n32, per_class
 
+    def set_probe(ang):
+        """Bracket the launches of angular class ``ang`` with HIP events (bench.py roofline leg)."""
+        state["probe"] = ang
+        state["stats"]["probe_events"] = []
+        state["stats"]["probe_classes"] = []
+
+    get_jk.set_probe = set_probe
     get_jk.quartet_counts = quartet_counts
     get_jk.stats = state["stats"]
     get_jk.layout = layout

@@ -13,7 +13,8 @@ def _setup(atom, basis, cart=False, unit="angstrom", cut64=1e-13, cut32=1e-13):
     from joltqc_amd.pyscf import jk as jkmod
     from joltqc_amd.pyscf.basis import BasisLayout
     mol = mole.Mole(atom=atom, basis=basis, cart=cart, unit=unit)
-    lay = BasisLayout.from_mol(mol)
+    from joltqc_amd.constants import tile_width
+    lay = BasisLayout.from_mol(mol, alignment=tile_width)
     return mol, lay, jkmod.generate_jk_kernel(lay, cutoff_fp64=cut64, cutoff_fp32=cut32)
 
 

@@ -28,7 +28,8 @@ def benzene():
 
 def check(name, atom, basis, cart=False, omega=None, hermi=1, oracle=True, unit="angstrom", reps=3):
     mol = mole.Mole(atom=atom, basis=basis, cart=cart, unit=unit)
-    lay = BasisLayout.from_mol(mol)
+    from joltqc_amd.constants import tile_width
+    lay = BasisLayout.from_mol(mol, alignment=tile_width)
     np.random.seed(9)
     nao = mol.nao
     dm = np.random.rand(nao, nao)
