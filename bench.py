@@ -117,7 +117,6 @@ def main():
         flops_by_ang[ang] = flops_by_ang.get(ang, 0) + (a + b) * quartet_flops(ang, npr or (1, 1, 1, 1))
     dom = max(flops_by_ang, key=flops_by_ang.get)
     total_flops = sum(flops_by_ang.values())
-    get_jk.set_probe(dom)
 
     barrier()
     t0 = time.perf_counter()
@@ -133,6 +132,14 @@ def main():
     dt = float(tmax.item())
     quartets, flops_all = float(nq[0].item()), float(nq[1].item())
 
+    # roofline leg: the dominant class kernel bracketed by HIP events on its own stream, class kernels
+    # launched back to back on ONE stream (in the timed region above they overlap on several streams,
+    # which makes a single kernel's duration ill-defined); same process, same inputs, right after the loop
+    get_jk.set_streams(1)
+    get_jk.set_probe(dom)
+    for _ in range(max(3, min(args.steps, 10))):
+        get_jk(mol, dm, hermi=1)
+    torch.cuda.synchronize()
     evs = get_jk.stats.get("probe_events", [])
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else None
     if rank == 0:
@@ -148,7 +155,7 @@ def main():
                        "whole_path_tflops": flops_all * args.steps / dt / 1e12,
                        "density": "rand(nao,nao) R R^T seed 9", "cutoff": 1e-13,
                        "parallelism": f"quartet strips round-robin over {world} rank(s) + 1 Fock all-reduce"},
-            "roofline": {"bound": "valu_fp64", "kernel": "jk_tile class (%d%d|%d%d)" % dom,
+            "roofline": {"bound": "valu_fp64", "kernel": "jk_tile*_%d%d%d%d" % dom,
                          "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VALU_PEAK_TFLOPS if achieved else None,
                          "kernel_ms": kern_ms, "kernel_gflop": flops_by_ang[dom] / 1e9, "traffic": None},

@@ -26,6 +26,7 @@ extern "C" {
 /* algorithm ids for jqc_gen_jk_kernel (reference router: jqc/backend/jk.py:57-115) */
 #define JQC_ALGO_1Q1T 0 /* one quartet per lane        (reference jk_1q1t.py / jk/1q1t.cu)  */
 #define JQC_ALGO_TILE 1 /* lane-group per quartet, LDS Fock tiles (replaces jk_1qnt.py / jk/1qnt.cu) */
+#define JQC_ALGO_TILE1Q 2 /* one quartet per lane inside the same LDS tile framework (small classes) */
 
 const char* jqc_last_error(void);
 const char* jqc_version(void);

@@ -22,6 +22,16 @@ def _table():
     return {}
 
 
+TILE1Q_MAX_NINT = 108     # above this the one-quartet-per-lane body spills to scratch on gfx950
+
+
+def nint(ang):
+    n = 1
+    for l in ang:
+        n *= (l + 1) * (l + 2) // 2
+    return n
+
+
 def class_key(ang):
     li, lj, lk, ll = ang
     return str(1000 * li + 100 * lj + 10 * lk + ll)
@@ -31,7 +41,12 @@ def select_algo(ang, fp32=False):
     t = _table().get("fp32" if fp32 else "fp64", {})
     forced = os.environ.get("JQC_JK_ALGO")
     if forced:
-        return _lib.ALGO_1Q1T if forced.lower() in ("0", "1q1t") else _lib.ALGO_TILE
+        f = forced.lower()
+        if f in ("0", "1q1t"):
+            return _lib.ALGO_1Q1T
+        if f in ("2", "tile1q"):
+            return _lib.ALGO_TILE1Q if nint(ang) <= TILE1Q_MAX_NINT else _lib.ALGO_TILE
+        return _lib.ALGO_TILE
     v = t.get(class_key(ang))
     if v is None:
         return _lib.ALGO_TILE

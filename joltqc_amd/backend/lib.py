@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(CSRC, "libjqc_hip.so")
 
 ALGO_1Q1T = 0
 ALGO_TILE = 1
+ALGO_TILE1Q = 2
 
 _lib = None
 _lock = threading.Lock()
@@ -46,6 +47,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the J/K and grid kernels)")
+        import torch  # noqa: F401  -- load torch's HIP runtime first so both share ONE libamdhip64 in the process
         L = ctypes.CDLL(LIB_PATH)
         c = ctypes
         vp, i32, i64, f32, f64 = c.c_void_p, c.c_int, c.c_int64, c.c_float, c.c_double

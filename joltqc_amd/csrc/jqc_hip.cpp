@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -87,6 +88,11 @@ int compile_to(const std::string& src_name, const std::vector<std::string>& defs
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-ffp-contract=fast",
                                      "-I" + g_src_dir};
     for (auto& d : defs) opts.push_back(d);
+    if (const char* extra = getenv("JQC_EXTRA_DEFS")) {      // tuning experiments: e.g. "-DMINW=3 -DECAP=32"
+        std::stringstream ss(extra);
+        std::string tok;
+        while (ss >> tok) opts.push_back(tok);
+    }
     std::vector<const char*> copts;
     for (auto& o : opts) copts.push_back(o.c_str());
     hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
@@ -246,6 +252,8 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
         const std::string txt = read_file(g_src_dir + "/" + f);
         for (unsigned char ch : txt) { h ^= ch; h *= 1099511628211ull; }
     }
+    if (const char* extra = getenv("JQC_EXTRA_DEFS"))
+        for (const char* c = extra; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
     char tag[32];
     snprintf(tag, sizeof tag, "%010llx", h & 0xffffffffffull);
     g_src_tag = tag;
@@ -279,14 +287,20 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
              fp32 ? "f32" : "f64");
     auto it = g_by_key.find(key);
     if (it != g_by_key.end() && (compile_only || g_kernels[it->second].fn)) return it->second;
-    const char* src = algo == JQC_ALGO_TILE ? "jk_tile.hip" : "jk_1q1t.hip";
-    const char* entry = algo == JQC_ALGO_TILE ? "jk_tile" : "jk_1q1t";
+    const bool tiled = algo == JQC_ALGO_TILE || algo == JQC_ALGO_TILE1Q;
+    const char* src = tiled ? "jk_tile.hip" : "jk_1q1t.hip";
+    // per-class entry-point name so that rocprofv3 --stats lists every class separately
+    char entry[64];
+    snprintf(entry, sizeof entry, "%s_%d%d%d%d%s", tiled ? (algo == JQC_ALGO_TILE1Q ? "jk_tile1q" : "jk_tile") : "jk_1q1t",
+             li, lj, lk, ll, fp32 ? "_f32" : "");
     const std::string out = g_cache_dir + "/" + key + "_" + g_src_tag + ".hsaco";
     if (!file_exists(out)) {
         std::vector<std::string> d = {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
                                       "-DLK=" + std::to_string(lk), "-DLL=" + std::to_string(ll),
                                       "-DDO_J=" + std::to_string(do_j), "-DDO_K=" + std::to_string(do_k),
-                                      "-DRYS_LR=" + std::to_string(rys_lr), "-DFP32=" + std::to_string(fp32)};
+                                      "-DRYS_LR=" + std::to_string(rys_lr), "-DFP32=" + std::to_string(fp32),
+                                      "-DTILE_1Q=" + std::to_string(algo == JQC_ALGO_TILE1Q ? 1 : 0),
+                                      std::string("-DKNAME=") + entry};
         int rc = compile_to(src, d, out);
         if (rc) return rc;
     }
@@ -340,7 +354,8 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
 {
     if (handle < 0 || handle >= (int)g_kernels.size() || !g_kernels[handle].fn)
         return fail(-1, "invalid kernel handle %d", handle);
-    if (g_kernels[handle].algo != JQC_ALGO_TILE) return fail(-1, "handle %d is not a tile kernel", handle);
+    if (g_kernels[handle].algo != JQC_ALGO_TILE && g_kernels[handle].algo != JQC_ALGO_TILE1Q)
+        return fail(-1, "handle %d is not a tile kernel", handle);
     if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
     if (ntasks <= 0 || nblocks <= 0) return 0;
     const Kernel& k = g_kernels[handle];

@@ -183,8 +183,11 @@ __device__ __forceinline__ void quartet_jk(const int nao, const real* __restrict
 
 // The task count lives in device memory (written by the screening kernel) so that the host never
 // synchronises between queue generation and the J/K launch; the grid is a bound, lanes stride.
+#ifndef KNAME
+#define KNAME jk_1q1t
+#endif
 extern "C" __global__ void __launch_bounds__(BLOCK)
-jk_1q1t(const int nao, const real* __restrict__ basis, const real* __restrict__ dm, double* __restrict__ vj,
+KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm, double* __restrict__ vj,
         double* __restrict__ vk, const real omega, const ushort4* __restrict__ quartets,
         const unsigned* __restrict__ ntasks_ptr, const int qstride, const int n_dm,
         const real* __restrict__ rys_cheb, const real* __restrict__ rys_large)

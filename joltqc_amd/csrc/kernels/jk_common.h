@@ -89,6 +89,26 @@ __device__ __forceinline__ void rys_roots(real x, real theta, real omega, const 
     }
 }
 
+// Fast reciprocal / reciprocal square root: hardware estimate + Newton steps (error < 2 ulp in f64,
+// < 1 ulp in f32), 5-7 instructions instead of the ~12-instruction IEEE division sequence.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    return r;
+}
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
 __device__ __forceinline__ void atomic_add_f64(double* p, double v)
 {
     // lowers to global_atomic_add_f64 (no CAS loop) on gfx950

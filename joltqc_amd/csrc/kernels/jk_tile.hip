@@ -32,6 +32,15 @@ constexpr int G = 256 / T;
 #ifndef ECAP
 #define ECAP 64
 #endif
+#ifndef TILE_1Q
+#define TILE_1Q 0   // 1: one quartet per lane inside the tile (small classes); 0: T row lanes per quartet
+#endif
+#ifndef ABLATE
+#define ABLATE 0    // timing-only builds (wrong results): 1 skip phase A, 2 skip phase B, 4 skip contraction, 8 no barriers
+#endif
+#ifndef MINW
+#define MINW 1      // waves per SIMD the register allocator must leave room for (measured: 1 is fastest)
+#endif
 constexpr int pick_nch()
 {
     for (int n = 1; n <= NFK; n++)
@@ -101,8 +110,11 @@ __device__ __forceinline__ void flush_tile(const double* __restrict__ src, doubl
 
 __device__ __forceinline__ void lds_add(double* p, double v) { atomicAdd(p, v); }   // ds_add_f64
 
-extern "C" __global__ void __launch_bounds__(256)
-jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ dm, double* __restrict__ vj,
+#ifndef KNAME
+#define KNAME jk_tile
+#endif
+extern "C" __global__ void __launch_bounds__(256, MINW)
+KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm, double* __restrict__ vj,
         double* __restrict__ vk, const real omega, const int* __restrict__ tasks, const int ntasks,
         const unsigned* __restrict__ tpair_sh, const float* __restrict__ tpair_q, const float* __restrict__ q_cond,
         const float* __restrict__ log_dm, const int nbas, const float cut_lo, const float cut_hi,
@@ -115,7 +127,9 @@ jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ 
     __shared__ unsigned short s_act[NQ];
     __shared__ real sDij[WJ * WI], sDkl[WL * WK], sDik[WI * WK], sDil[WI * WL], sDjk[WJ * WK], sDjl[WJ * WL];
     __shared__ double sJij[WJ * WI], sJkl[WL * WK], sKik[WI * WK], sKil[WI * WL], sKjk[WJ * WK], sKjl[WJ * WL];
+#if !TILE_1Q
     __shared__ real sT[G * NROOTS * 3 * NT2];
+#endif
 
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -179,6 +193,7 @@ jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ 
     const int npi = (int)bi0[10], npj = (int)bj0[10], npk = (int)bk0[10], npl = (int)bl0[10];
     const int i0 = (int)bi0[3], j0 = (int)bj0[3], k0 = (int)bk0[3], l0 = (int)bl0[3];
 
+#if !TILE_1Q
     const int slot = tid / T, t = tid - slot * T;
     const bool lane_on = slot < G;
     const int per = (nact + G - 1) / G;
@@ -188,6 +203,9 @@ jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ 
     real* __restrict__ myT = sT + slot * (NROOTS * 3 * NT2);
     const size_t nao2 = (size_t)nao * nao;
 
+#else
+    const size_t nao2 = (size_t)nao * nao;
+#endif
     for (int idm = 0; idm < n_dm; idm++) {
         const real* __restrict__ D = dm + idm * nao2;
         __syncthreads();
@@ -210,6 +228,152 @@ jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ 
 #endif
         __syncthreads();
 
+#if TILE_1Q
+        // ---------------- one quartet per lane: everything in registers, then LDS Fock tiles
+        if (tid < nact) {
+            const int qd = s_act[tid];
+            const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = qd / (TSI * TSJ * TSL);
+            const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
+            const real* __restrict__ bi = basis + ish * BASIS_STRIDE;
+            const real* __restrict__ bj = basis + jsh * BASIS_STRIDE;
+            const real* __restrict__ bk = basis + ksh * BASIS_STRIDE;
+            const real* __restrict__ bl = basis + lsh * BASIS_STRIDE;
+            const real rix = bi[0], riy = bi[1], riz = bi[2];
+            const real rkx = bk[0], rky = bk[1], rkz = bk[2];
+            const real rij[3] = {bj[0] - rix, bj[1] - riy, bj[2] - riz};
+            const real rkl[3] = {bl[0] - rkx, bl[1] - rky, bl[2] - rkz};
+            const real rr_ij = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2];
+            const real rr_kl = rkl[0] * rkl[0] + rkl[1] * rkl[1] + rkl[2] * rkl[2];
+            real fac = real(34.98683665524972497);
+            if (ish == jsh) fac *= real(0.5);
+            if (ksh == lsh) fac *= real(0.5);
+            if (ish == ksh && jsh == lsh) fac *= real(0.5);
+            real I[NINT];
+#pragma unroll
+            for (int n = 0; n < NINT; n++) I[n] = 0;
+            for (int kp = 0; kp < npk; kp++)
+            for (int lp = 0; lp < npl; lp++) {
+                const real ck = bk[4 + 2 * kp], ak = bk[5 + 2 * kp];
+                const real cl = bl[4 + 2 * lp], al = bl[5 + 2 * lp];
+                const real akl = ak + al, inv_akl = fast_rcp(akl), al_akl = al * inv_akl;
+                const real ckcl = ck * cl * exp(-ak * al_akl * rr_kl);
+                for (int ip = 0; ip < npi; ip++)
+                for (int jp = 0; jp < npj; jp++) {
+                    const real cI = bi[4 + 2 * ip], ai = bi[5 + 2 * ip];
+                    const real cJ = bj[4 + 2 * jp], aj = bj[5 + 2 * jp];
+                    const real aij = ai + aj, inv_aij = fast_rcp(aij), aj_aij = aj * inv_aij;
+                    const real cicj = fac * cI * cJ * exp(-ai * aj_aij * rr_ij);
+                    const real rpa[3] = {rij[0] * aj_aij, rij[1] * aj_aij, rij[2] * aj_aij};
+                    const real rqc[3] = {rkl[0] * al_akl, rkl[1] * al_akl, rkl[2] * al_akl};
+                    const real rpq[3] = {rpa[0] + rix - rqc[0] - rkx, rpa[1] + riy - rqc[1] - rky,
+                                         rpa[2] + riz - rqc[2] - rkz};
+                    const real rr = rpq[0] * rpq[0] + rpq[1] * rpq[1] + rpq[2] * rpq[2];
+                    const real sinv = fast_rsqrt(aij + akl);
+                    const real inv = sinv * sinv;
+                    const real theta = aij * akl * inv;
+                    const real gy0 = cicj * inv_aij * inv_akl * sinv;
+                    real rw[2 * NROOTS];
+                    rys_roots(rr, theta, omega, rys_cheb, rys_large, rw);
+                    for (int ir = 0; ir < NROOTS; ir++) {
+                        const real t2 = rw[2 * ir], wt = rw[2 * ir + 1];
+                        const real rt_aa = t2 * inv;
+                        const real rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
+                        const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
+                        const real b01 = real(0.5) * inv_akl * (real(1) - rt_akl);
+                        const real b00 = real(0.5) * rt_aa;
+                        real gx[GSIZE], gy[GSIZE], gz[GSIZE];
+                        axis_integrals(ckcl, rpa[0] - rt_aij * rpq[0], rqc[0] + rt_akl * rpq[0], b10, b01, b00, rij[0], rkl[0], gx);
+                        axis_integrals(gy0, rpa[1] - rt_aij * rpq[1], rqc[1] + rt_akl * rpq[1], b10, b01, b00, rij[1], rkl[1], gy);
+                        axis_integrals(wt, rpa[2] - rt_aij * rpq[2], rqc[2] + rt_akl * rpq[2], b10, b01, b00, rij[2], rkl[2], gz);
+#pragma unroll
+                        for (int i = 0; i < NFI; i++)
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                        for (int k = 0; k < NFK; k++)
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) {
+                            const int ax = TI.x[i] * GS_I + TJ.x[j] * GS_J + TK.x[k] * GS_K + TL.x[l];
+                            const int ay = TI.y[i] * GS_I + TJ.y[j] * GS_J + TK.y[k] * GS_K + TL.y[l];
+                            const int az = TI.z[i] * GS_I + TJ.z[j] * GS_J + TK.z[k] * GS_K + TL.z[l];
+                            I[((i * NFJ + j) * NFK + k) * NFL + l] += gx[ax] * gy[ay] * gz[az];
+                        }
+                    }
+                }
+            }
+            const int iA = a * NFI, jA = b * NFJ, kA = c * NFK, lA = d * NFL;
+#if DO_J
+            {
+                real jkl[NFK * NFL], dkl[NFK * NFL];
+#pragma unroll
+                for (int k = 0; k < NFK; k++)
+#pragma unroll
+                    for (int l = 0; l < NFL; l++) { jkl[k * NFL + l] = 0; dkl[k * NFL + l] = sDkl[(lA + l) * WK + kA + k]; }
+#pragma unroll
+                for (int i = 0; i < NFI; i++)
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++) {
+                        const real dij = sDij[(jA + j) * WI + iA + i];
+                        real s = 0;
+#pragma unroll
+                        for (int n = 0; n < NFK * NFL; n++) {
+                            const real v = I[(i * NFJ + j) * NFK * NFL + n];
+                            s += v * dkl[n];
+                            jkl[n] += v * dij;
+                        }
+                        lds_add(&sJij[(jA + j) * WI + iA + i], (double)s);
+                    }
+#pragma unroll
+                for (int k = 0; k < NFK; k++)
+#pragma unroll
+                    for (int l = 0; l < NFL; l++) lds_add(&sJkl[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
+            }
+#endif
+#if DO_K
+            {
+                real kjk[NFJ * NFK], kjl[NFJ * NFL], djk[NFJ * NFK], djl[NFJ * NFL];
+#pragma unroll
+                for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                    for (int k = 0; k < NFK; k++) { kjk[j * NFK + k] = 0; djk[j * NFK + k] = sDjk[(jA + j) * WK + kA + k]; }
+#pragma unroll
+                    for (int l = 0; l < NFL; l++) { kjl[j * NFL + l] = 0; djl[j * NFL + l] = sDjl[(jA + j) * WL + lA + l]; }
+                }
+#pragma unroll
+                for (int i = 0; i < NFI; i++) {
+                    real kik[NFK], kil[NFL], dik[NFK], dil[NFL];
+#pragma unroll
+                    for (int k = 0; k < NFK; k++) { kik[k] = 0; dik[k] = sDik[(iA + i) * WK + kA + k]; }
+#pragma unroll
+                    for (int l = 0; l < NFL; l++) { kil[l] = 0; dil[l] = sDil[(iA + i) * WL + lA + l]; }
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                        for (int k = 0; k < NFK; k++)
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) {
+                                const real v = I[((i * NFJ + j) * NFK + k) * NFL + l];
+                                kik[k] += v * djl[j * NFL + l];
+                                kil[l] += v * djk[j * NFK + k];
+                                kjk[j * NFK + k] += v * dil[l];
+                                kjl[j * NFL + l] += v * dik[k];
+                            }
+#pragma unroll
+                    for (int k = 0; k < NFK; k++) lds_add(&sKik[(iA + i) * WK + kA + k], (double)kik[k]);
+#pragma unroll
+                    for (int l = 0; l < NFL; l++) lds_add(&sKil[(iA + i) * WL + lA + l], (double)kil[l]);
+                }
+#pragma unroll
+                for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                    for (int k = 0; k < NFK; k++) lds_add(&sKjk[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
+#pragma unroll
+                    for (int l = 0; l < NFL; l++) lds_add(&sKjl[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
+                }
+            }
+#endif
+        }
+#else
 #pragma unroll
         for (int CH = 0; CH < NCH; CH++) {
             // register accumulators carried across consecutive quartets of this lane
@@ -273,20 +437,21 @@ jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ 
                 for (int ip = 0; ip < npi; ip++)
                 for (int jp = 0; jp < npj; jp++) {
                     // ---------------- phase A: job lanes: one root + one axis TRR each
-                    if (on) {
+                    if (on && !(ABLATE & 1)) {
                         for (int job = t; job < 3 * NROOTS; job += T) {
                             const int r = job / 3, ax = job - r * 3;
                             const real ck = bk[4 + 2 * kp], ak = bk[5 + 2 * kp];
                             const real cl = bl[4 + 2 * lp], al = bl[5 + 2 * lp];
                             const real cI = bi[4 + 2 * ip], ai = bi[5 + 2 * ip];
                             const real cJ = bj[4 + 2 * jp], aj = bj[5 + 2 * jp];
-                            const real akl = ak + al, inv_akl = real(1) / akl, al_akl = al * inv_akl;
-                            const real aij = ai + aj, inv_aij = real(1) / aij, aj_aij = aj * inv_aij;
+                            const real akl = ak + al, inv_akl = fast_rcp(akl), al_akl = al * inv_akl;
+                            const real aij = ai + aj, inv_aij = fast_rcp(aij), aj_aij = aj * inv_aij;
                             const real rpq0 = rij[0] * aj_aij + rix - rkl[0] * al_akl - rkx;
                             const real rpq1 = rij[1] * aj_aij + riy - rkl[1] * al_akl - rky;
                             const real rpq2 = rij[2] * aj_aij + riz - rkl[2] * al_akl - rkz;
                             const real rr = rpq0 * rpq0 + rpq1 * rpq1 + rpq2 * rpq2;
-                            const real inv = real(1) / (aij + akl);
+                            const real sinv = fast_rsqrt(aij + akl);
+                            const real inv = sinv * sinv;
                             const real theta = aij * akl * inv;
                             real t2, wt;
                             rys_root_one(rr, theta, omega, r, rys_cheb, rys_large, t2, wt);
@@ -302,7 +467,7 @@ jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ 
                             const real cp = rkl_a * al_akl + rt_akl * rpq_a;
                             real g0;
                             if (ax == 0) g0 = ck * cl * exp(-ak * al_akl * rr_kl);
-                            else if (ax == 1) g0 = fac * cI * cJ * exp(-ai * aj_aij * rr_ij) * inv_aij * inv_akl * sqrt(inv);
+                            else if (ax == 1) g0 = fac * cI * cJ * exp(-ai * aj_aij * rr_ij) * inv_aij * inv_akl * sinv;
                             else g0 = wt;
                             real tt[LIJ + 1][LKL + 1];
                             tt[0][0] = g0;
@@ -328,9 +493,9 @@ jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ 
                                 for (int cc = 0; cc <= LKL; cc++) dst[q * (LKL + 1) + cc] = tt[q][cc];
                         }
                     }
-                    __syncthreads();
+                    if (!(ABLATE & 8)) __syncthreads();
                     // ---------------- phase B: row lanes: own bra slice, ket HRR, integral accumulation
-                    if (on) {
+                    if (on && !(ABLATE & 2)) {
                         for (int r = 0; r < NROOTS; r++) {
                             real gk[3][LK + 1][LL + 1];
 #pragma unroll
@@ -363,7 +528,11 @@ jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ 
                                 }
                         }
                     }
-                    __syncthreads();
+                    if (!(ABLATE & 8)) __syncthreads();
+                }
+                if (ABLATE & 4) {
+                    if (on) { real s = 0; for (int e = 0; e < E; e++) s += acc[e]; if (s == real(1.2345)) lds_add(&sJij[0], (double)s); }
+                    continue;
                 }
 
                 // ---------------- contraction with the density sub-blocks, accumulation in the LDS Fock tiles
@@ -457,6 +626,7 @@ jk_tile(const int nao, const real* __restrict__ basis, const real* __restrict__ 
             }
 #endif
         }
+#endif  // TILE_1Q
         __syncthreads();
         // ---- one coalesced pass of global f64 atomics per Fock sub-block
 #if DO_J

@@ -331,7 +331,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
     # the tiled kernels need every (l, nprim) group padded to its tile width
     tiled_layout = all((layout.group_offset[g + 1] - layout.group_offset[g]) % tile_width(int(layout.group_key[g, 0])) == 0
                        for g in range(layout.ngroups))
-    state = {"pairs": {}, "tiles": {}, "queue": None, "stats": {}, "probe": None, "plan_cache": {}, "streams": None}
+    state = {"pairs": {}, "tiles": {}, "queue": None, "stats": {}, "probe": None, "plan_cache": {}, "streams": None,
+             "nstreams": N_STREAMS}
 
     def get_jk(mol_ref=None, dm=None, hermi=0, vhfopt=None, with_j=True, with_k=True, omega=None, verbose=None):
         """Compute J, K; compatible with ``pyscf.scf.hf.get_jk`` / the reference closure (jk.py:109-118).
@@ -373,7 +374,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
         vk_p = vk.data_ptr() if with_k else None
         b64 = layout.basis_data_fp64["packed"]
         b32 = layout.basis_data_fp32["packed"] if mixed else None
-        is_tile = lambda ang: _router.select_algo(ang) == _lib.ALGO_TILE
+        is_tile = lambda ang: _router.select_algo(ang) in (_lib.ALGO_TILE, _lib.ALGO_TILE1Q)
         n_launch = 0
         counter_bufs = []
         tile_counts = None
@@ -405,8 +406,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
             if entry is not None:
                 order, tabs_d, tplans = entry["order"], entry["tabs_d"], entry["plans"]
                 tile_counts = torch.zeros((2, entry["nrows"]), dtype=torch.int64, device=dev)
-                if state["streams"] is None:
-                    state["streams"] = [torch.cuda.Stream(device=dev) for _ in range(N_STREAMS)]
+                if state["streams"] is None or len(state["streams"]) != state["nstreams"]:
+                    state["streams"] = [torch.cuda.Stream(device=dev) for _ in range(state["nstreams"])]
                 side = state["streams"]
                 cur = torch.cuda.current_stream()
                 ev = torch.cuda.Event()
@@ -418,7 +419,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     tab, nblk, _ = tplans[ang]
                     sid = side[n % len(side)]
                     sp = sid.cuda_stream
-                    h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=_lib.ALGO_TILE)
+                    h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False,
+                                                algo=_router.select_algo(ang))
                     probing = state["probe"] is not None and (state["probe"] == "all" or tuple(state["probe"]) == tuple(ang))
                     if probing:
                         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -435,7 +437,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     n_launch += 1
                     if mixed:
                         h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True,
-                                                    algo=_lib.ALGO_TILE)
+                                                    algo=_router.select_algo(ang, True))
                         _lib.check(L.jqc_jk_tile_launch(h32, nao, b32.data_ptr(), dms_fp32.data_ptr(), vj_p, vk_p, om,
                                                         tabs_d.data_ptr() + row * 32, tab.shape[0], nblk,
                                                         tt.sh.data_ptr(), tt.q.data_ptr(), tt.q_dev.data_ptr(),
@@ -558,6 +560,11 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
         state["stats"]["probe_events"] = []
         state["stats"]["probe_classes"] = []
 
+    def set_streams(n):
+        """Number of HIP streams the class kernels are spread over (1 = serial launches)."""
+        state["nstreams"] = max(1, int(n))
+
+    get_jk.set_streams = set_streams
     get_jk.set_probe = set_probe
     get_jk.quartet_counts = quartet_counts
     get_jk.stats = state["stats"]

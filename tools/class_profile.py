@@ -3,7 +3,7 @@ usage: JQC_STREAMS=1 python tools/class_profile.py [benzene|<xyz name>] [basis]"
 import os, sys, json
 os.environ.setdefault("JQC_STREAMS", "1")
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import load_workload
 from joltqc_amd.constants import tile_width
 from joltqc_amd.pyscf import jk as jkmod

@@ -3,7 +3,7 @@ Logs progressively to gpurun_out/check.log."""
 import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from joltqc_amd.gto import mole
 from joltqc_amd.pyscf.basis import BasisLayout
 from joltqc_amd.pyscf import jk as jkmod
