@@ -93,6 +93,40 @@ int jqc_shell_block_max(const double* mat_d, int n_dm, int nao, const int32_t* a
 int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d, int npairs, double omega,
                 double* out_d, void* stream);
 
+/* ------------------------------------------------------------------------------------------ DFT grid path
+ * Grid coordinates are SoA double[3][ngrids], ngrids a multiple of 256 (reference: jqc/backend/rks.py:84-86),
+ * sorted so that each block of 256 points is spatially compact (jqc/pyscf/rks.py:148-168).
+ *
+ * jqc_dft_ao_screen  replaces estimate_log_aovalue (jqc/backend/rks.py:167-242, dft/estimate_log_aovalue.cu:36):
+ *   per block the shells whose log-max AO estimate exceeds log_cutoff, ascending, zero-width (padding) shells excluded:
+ *   shell_list uint16[nblk*nbas], row_of int32[nblk*nbas] (first AO row of the shell inside the block),
+ *   nshl int32[nblk], nrow int32[nblk].
+ * jqc_dft_eval_ao    AO values (ncomp=1) or values+gradient (ncomp=4) of blocks [blk0, blk0+nblk) into the workspace
+ *   ws double[ncomp][rows][256] (comp_stride = rows*256 doubles), block b starts at row row_base[b] (multiple of 16,
+ *   block rows padded to a multiple of 16 with zeros); ao_idx int32[rows] = internal AO index of a row or -1.
+ * jqc_dft_rho        replaces eval_rho (jqc/backend/rks.py:40-96, dft/eval_rho.cu:58): rho[ndim][ngrids] +=, ndim 1/4/5,
+ *   dm double[nao*nao] symmetric, internal Cartesian order.
+ * jqc_dft_vxc        replaces eval_vxc (jqc/backend/rks.py:104-160, dft/eval_vxc.cu:87): vmat[nao*nao] += the FULL
+ *   symmetric V (the reference accumulates the upper triangle and symmetrises afterwards); wv[ndim][ngrids] already
+ *   contains the quadrature weights.
+ * jqc_vv10           replaces vv10_kernel (jqc/backend/rks.py:250-335, dft/vv10.cu:29): F,U,W double[ngrids]. */
+int jqc_dft_ao_screen(const double* coords_d, int ngrids, const double* basis_d, const int32_t* ao_loc_d, int nbas,
+                      float log_cutoff, uint16_t* shell_list_d, int32_t* row_of_d, int32_t* nshl_d, int32_t* nrow_d,
+                      void* stream);
+int jqc_dft_eval_ao(const double* coords_d, int ngrids, const double* basis_d, int nbas, int blk0, int nblk,
+                    const uint16_t* shell_list_d, const int32_t* row_of_d, const int32_t* nshl_d, const int32_t* nrow_d,
+                    const int64_t* row_base_d, int ncomp, int64_t comp_stride, double* ws_d, int32_t* ao_idx_d,
+                    void* stream);
+int jqc_dft_rho(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
+                const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, int ndim, double* rho_d,
+                void* stream);
+int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
+                const double* ws_d, const int32_t* ao_idx_d, const double* wv_d, int ndim, int nao, double* vmat_d,
+                void* stream);
+int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, const double* coords_d,
+             const double* W0p_d, const double* W0_d, const double* K_d, const double* Kp_d, const double* RpW_d,
+             int vvngrids, int ngrids, int fp32, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

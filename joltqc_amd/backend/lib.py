@@ -28,9 +28,10 @@ _rys_uploaded = False
 def build_library(force=False):
     """hipcc-compile the C-ABI library in-tree (cross-compiles for gfx950 without a GPU)."""
     src = os.path.join(CSRC, "jqc_hip.cpp")
+    inc = os.path.join(CSRC, "dft_kernels.inc")
     hdr = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "jqc_hip.h")
     if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(inc))):
         return LIB_PATH
     cmd = ["hipcc", "-O2", "-shared", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", src,
            "-o", LIB_PATH, "-lhiprtc"]
@@ -63,6 +64,11 @@ def lib():
         L.jqc_screen_jk_tasks.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp]
         L.jqc_shell_block_max.argtypes = [vp, i32, i32, vp, i32, vp, vp]
         L.jqc_schwarz.argtypes = [i32, i32, vp, vp, i32, f64, vp, vp]
+        L.jqc_dft_ao_screen.argtypes = [vp, i32, vp, vp, i32, f32, vp, vp, vp, vp, vp]
+        L.jqc_dft_eval_ao.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp]
+        L.jqc_dft_rho.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp]
+        L.jqc_dft_vxc.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp]
+        L.jqc_vv10.argtypes = [vp] * 10 + [i32, i32, i32, vp]
         os.makedirs(KERNEL_CACHE, exist_ok=True)
         L.jqc_set_kernel_dirs(KERNEL_SRC.encode(), KERNEL_CACHE.encode())
         _lib = L

@@ -232,6 +232,8 @@ shell_block_max_kernel(const double* __restrict__ mat, const int n_dm, const int
     out[idx] = (float)m;
 }
 
+#include "dft_kernels.inc"
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -429,6 +431,74 @@ int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d
     void* args[] = {&basis_d, &pair_sh_d, &npairs, &omega, &out_d, &cheb, &large};
     HIP_OK(hipModuleLaunchKernel(kp->fn, (unsigned)((npairs + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args,
                                  nullptr));
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ DFT grid path
+int jqc_dft_ao_screen(const double* coords_d, int ngrids, const double* basis_d, const int32_t* ao_loc_d, int nbas,
+                      float log_cutoff, uint16_t* shell_list_d, int32_t* row_of_d, int32_t* nshl_d, int32_t* nrow_d,
+                      void* stream)
+{
+    if (ngrids % NG) return fail(-1, "ngrids (%d) must be a multiple of %d", ngrids, NG);
+    if (nbas > 16384) return fail(-1, "more than 16384 shells are not supported by the grid screening kernel");
+    if (ngrids == 0) return 0;
+    hipLaunchKernelGGL(ao_screen_kernel, dim3(ngrids / NG), dim3(256), 0, (hipStream_t)stream, coords_d, ngrids, basis_d,
+                       ao_loc_d, nbas, log_cutoff, shell_list_d, row_of_d, nshl_d, nrow_d);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int jqc_dft_eval_ao(const double* coords_d, int ngrids, const double* basis_d, int nbas, int blk0, int nblk,
+                    const uint16_t* shell_list_d, const int32_t* row_of_d, const int32_t* nshl_d, const int32_t* nrow_d,
+                    const int64_t* row_base_d, int ncomp, int64_t comp_stride, double* ws_d, int32_t* ao_idx_d,
+                    void* stream)
+{
+    if (nblk <= 0) return 0;
+    hipLaunchKernelGGL(eval_ao_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, coords_d, ngrids, basis_d, nbas,
+                       blk0, shell_list_d, row_of_d, nshl_d, nrow_d, (const long long*)row_base_d, ncomp,
+                       (long long)comp_stride, ws_d, ao_idx_d);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int jqc_dft_rho(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
+                const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, int ndim, double* rho_d,
+                void* stream)
+{
+    if (nblk <= 0) return 0;
+    if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
+    hipLaunchKernelGGL(rho_mfma_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
+                const double* ws_d, const int32_t* ao_idx_d, const double* wv_d, int ndim, int nao, double* vmat_d,
+                void* stream)
+{
+    if (nblk <= 0) return 0;
+    if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
+    hipLaunchKernelGGL(vxc_mfma_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, wv_d, ndim, nao, vmat_d);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, const double* coords_d,
+             const double* W0p_d, const double* W0_d, const double* K_d, const double* Kp_d, const double* RpW_d,
+             int vvngrids, int ngrids, int fp32, void* stream)
+{
+    if (ngrids % NG || vvngrids % NG) return fail(-1, "VV10 grids must be padded to a multiple of %d", NG);
+    if (ngrids == 0) return 0;
+    if (fp32)
+        hipLaunchKernelGGL(vv10_kernel<float>, dim3(ngrids / NG), dim3(256), 0, (hipStream_t)stream, F_d, U_d, W_d,
+                           vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids);
+    else
+        hipLaunchKernelGGL(vv10_kernel<double>, dim3(ngrids / NG), dim3(256), 0, (hipStream_t)stream, F_d, U_d, W_d,
+                           vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 

@@ -130,6 +130,10 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #if !TILE_1Q
     __shared__ real sT[G * NROOTS * 3 * NT2];
 #endif
+    // shell rows of the four tiles and per-primitive-pair prefactors {c_a c_b K_ab, 1/(a+b), a+b}:
+    // every exp / reciprocal of the pair prefactors is evaluated once per workgroup, not once per quartet
+    __shared__ real sBas[(TSI + TSJ + TSK + TSL) * BASIS_STRIDE];
+    __shared__ real sPB[TSI * TSJ * 9 * 3], sPK[TSK * TSL * 9 * 3];
 
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -192,6 +196,28 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     const real* __restrict__ bl0 = basis + lsh0 * BASIS_STRIDE;
     const int npi = (int)bi0[10], npj = (int)bj0[10], npk = (int)bk0[10], npl = (int)bl0[10];
     const int i0 = (int)bi0[3], j0 = (int)bj0[3], k0 = (int)bk0[3], l0 = (int)bl0[3];
+    constexpr int OFF_J = TSI * BASIS_STRIDE, OFF_K = (TSI + TSJ) * BASIS_STRIDE, OFF_L = (TSI + TSJ + TSK) * BASIS_STRIDE;
+    for (int n = tid; n < (TSI + TSJ + TSK + TSL) * BASIS_STRIDE; n += 256) {
+        const int sl = n / BASIS_STRIDE, w = n - sl * BASIS_STRIDE;
+        const int sh = sl < TSI ? ish0 + sl : sl < TSI + TSJ ? jsh0 + sl - TSI
+                     : sl < TSI + TSJ + TSK ? ksh0 + sl - TSI - TSJ : lsh0 + sl - TSI - TSJ - TSK;
+        sBas[n] = basis[sh * BASIS_STRIDE + w];
+    }
+    __syncthreads();
+    for (int n = tid; n < (TSI * TSJ + TSK * TSL) * 9; n += 256) {
+        const bool bra = n < TSI * TSJ * 9;
+        const int m = bra ? n : n - TSI * TSJ * 9;
+        const int pr = m / 9, pp = m - pr * 9, p1 = pp / 3, p2 = pp - p1 * 3;
+        const real* s1 = bra ? sBas + (pr / TSJ) * BASIS_STRIDE : sBas + OFF_K + (pr / TSL) * BASIS_STRIDE;
+        const real* s2 = bra ? sBas + OFF_J + (pr % TSJ) * BASIS_STRIDE : sBas + OFF_L + (pr % TSL) * BASIS_STRIDE;
+        const real dx = s2[0] - s1[0], dy = s2[1] - s1[1], dz = s2[2] - s1[2];
+        const real a1 = s1[5 + 2 * p1], a2 = s2[5 + 2 * p2];
+        const real asum = a1 + a2, inv = fast_rcp(asum);
+        const real val = s1[4 + 2 * p1] * s2[4 + 2 * p2] * exp(-a1 * a2 * inv * (dx * dx + dy * dy + dz * dz));
+        real* dst = (bra ? sPB : sPK) + m * 3;
+        dst[0] = val; dst[1] = inv; dst[2] = asum;
+    }
+    __syncthreads();
 
 #if !TILE_1Q
     const int slot = tid / T, t = tid - slot * T;
@@ -234,16 +260,16 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             const int qd = s_act[tid];
             const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = qd / (TSI * TSJ * TSL);
             const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
-            const real* __restrict__ bi = basis + ish * BASIS_STRIDE;
-            const real* __restrict__ bj = basis + jsh * BASIS_STRIDE;
-            const real* __restrict__ bk = basis + ksh * BASIS_STRIDE;
-            const real* __restrict__ bl = basis + lsh * BASIS_STRIDE;
+            const real* bi = sBas + a * BASIS_STRIDE;
+            const real* bj = sBas + OFF_J + b * BASIS_STRIDE;
+            const real* bk = sBas + OFF_K + c * BASIS_STRIDE;
+            const real* bl = sBas + OFF_L + d * BASIS_STRIDE;
+            const real* pb = sPB + (a * TSJ + b) * 27;
+            const real* pk = sPK + (c * TSL + d) * 27;
             const real rix = bi[0], riy = bi[1], riz = bi[2];
             const real rkx = bk[0], rky = bk[1], rkz = bk[2];
             const real rij[3] = {bj[0] - rix, bj[1] - riy, bj[2] - riz};
             const real rkl[3] = {bl[0] - rkx, bl[1] - rky, bl[2] - rkz};
-            const real rr_ij = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2];
-            const real rr_kl = rkl[0] * rkl[0] + rkl[1] * rkl[1] + rkl[2] * rkl[2];
             real fac = real(34.98683665524972497);
             if (ish == jsh) fac *= real(0.5);
             if (ksh == lsh) fac *= real(0.5);
@@ -253,16 +279,13 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             for (int n = 0; n < NINT; n++) I[n] = 0;
             for (int kp = 0; kp < npk; kp++)
             for (int lp = 0; lp < npl; lp++) {
-                const real ck = bk[4 + 2 * kp], ak = bk[5 + 2 * kp];
-                const real cl = bl[4 + 2 * lp], al = bl[5 + 2 * lp];
-                const real akl = ak + al, inv_akl = fast_rcp(akl), al_akl = al * inv_akl;
-                const real ckcl = ck * cl * exp(-ak * al_akl * rr_kl);
+                const real ckcl = pk[(kp * 3 + lp) * 3], inv_akl = pk[(kp * 3 + lp) * 3 + 1], akl = pk[(kp * 3 + lp) * 3 + 2];
+                const real al_akl = bl[5 + 2 * lp] * inv_akl;
                 for (int ip = 0; ip < npi; ip++)
                 for (int jp = 0; jp < npj; jp++) {
-                    const real cI = bi[4 + 2 * ip], ai = bi[5 + 2 * ip];
-                    const real cJ = bj[4 + 2 * jp], aj = bj[5 + 2 * jp];
-                    const real aij = ai + aj, inv_aij = fast_rcp(aij), aj_aij = aj * inv_aij;
-                    const real cicj = fac * cI * cJ * exp(-ai * aj_aij * rr_ij);
+                    const real inv_aij = pb[(ip * 3 + jp) * 3 + 1], aij = pb[(ip * 3 + jp) * 3 + 2];
+                    const real aj_aij = bj[5 + 2 * jp] * inv_aij;
+                    const real cicj = fac * pb[(ip * 3 + jp) * 3];
                     const real rpa[3] = {rij[0] * aj_aij, rij[1] * aj_aij, rij[2] * aj_aij};
                     const real rqc[3] = {rkl[0] * al_akl, rkl[1] * al_akl, rkl[2] * al_akl};
                     const real rpq[3] = {rpa[0] + rix - rqc[0] - rkx, rpa[1] + riy - rqc[1] - rky,
@@ -396,16 +419,16 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     a = qd % TSI; b = (qd / TSI) % TSJ; d = (qd / (TSI * TSJ)) % TSL; c = qd / (TSI * TSJ * TSL);
                 }
                 const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
-                const real* __restrict__ bi = basis + ish * BASIS_STRIDE;
-                const real* __restrict__ bj = basis + jsh * BASIS_STRIDE;
-                const real* __restrict__ bk = basis + ksh * BASIS_STRIDE;
-                const real* __restrict__ bl = basis + lsh * BASIS_STRIDE;
+                const real* bi = sBas + a * BASIS_STRIDE;
+                const real* bj = sBas + OFF_J + b * BASIS_STRIDE;
+                const real* bk = sBas + OFF_K + c * BASIS_STRIDE;
+                const real* bl = sBas + OFF_L + d * BASIS_STRIDE;
+                const real* pb = sPB + (a * TSJ + b) * 27;
+                const real* pk = sPK + (c * TSL + d) * 27;
                 const real rix = bi[0], riy = bi[1], riz = bi[2];
                 const real rkx = bk[0], rky = bk[1], rkz = bk[2];
                 const real rij[3] = {bj[0] - rix, bj[1] - riy, bj[2] - riz};
                 const real rkl[3] = {bl[0] - rkx, bl[1] - rky, bl[2] - rkz};
-                const real rr_ij = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2];
-                const real rr_kl = rkl[0] * rkl[0] + rkl[1] * rkl[1] + rkl[2] * rkl[2];
                 real fac = real(34.98683665524972497);
                 if (ish == jsh) fac *= real(0.5);
                 if (ksh == lsh) fac *= real(0.5);
@@ -440,12 +463,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     if (on && !(ABLATE & 1)) {
                         for (int job = t; job < 3 * NROOTS; job += T) {
                             const int r = job / 3, ax = job - r * 3;
-                            const real ck = bk[4 + 2 * kp], ak = bk[5 + 2 * kp];
-                            const real cl = bl[4 + 2 * lp], al = bl[5 + 2 * lp];
-                            const real cI = bi[4 + 2 * ip], ai = bi[5 + 2 * ip];
-                            const real cJ = bj[4 + 2 * jp], aj = bj[5 + 2 * jp];
-                            const real akl = ak + al, inv_akl = fast_rcp(akl), al_akl = al * inv_akl;
-                            const real aij = ai + aj, inv_aij = fast_rcp(aij), aj_aij = aj * inv_aij;
+                            const real ckcl = pk[(kp * 3 + lp) * 3], inv_akl = pk[(kp * 3 + lp) * 3 + 1], akl = pk[(kp * 3 + lp) * 3 + 2];
+                            const real cicj = pb[(ip * 3 + jp) * 3], inv_aij = pb[(ip * 3 + jp) * 3 + 1], aij = pb[(ip * 3 + jp) * 3 + 2];
+                            const real al_akl = bl[5 + 2 * lp] * inv_akl, aj_aij = bj[5 + 2 * jp] * inv_aij;
                             const real rpq0 = rij[0] * aj_aij + rix - rkl[0] * al_akl - rkx;
                             const real rpq1 = rij[1] * aj_aij + riy - rkl[1] * al_akl - rky;
                             const real rpq2 = rij[2] * aj_aij + riz - rkl[2] * al_akl - rkz;
@@ -454,7 +474,8 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             const real inv = sinv * sinv;
                             const real theta = aij * akl * inv;
                             real t2, wt;
-                            rys_root_one(rr, theta, omega, r, rys_cheb, rys_large, t2, wt);
+                            if (ABLATE & 16) { t2 = real(0.3) + real(0.01) * r; wt = real(0.5); }
+                            else rys_root_one(rr, theta, omega, r, rys_cheb, rys_large, t2, wt);
                             const real rt_aa = t2 * inv;
                             const real rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
                             const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
@@ -466,11 +487,17 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             const real c0 = rij_a * aj_aij - rt_aij * rpq_a;
                             const real cp = rkl_a * al_akl + rt_akl * rpq_a;
                             real g0;
-                            if (ax == 0) g0 = ck * cl * exp(-ak * al_akl * rr_kl);
-                            else if (ax == 1) g0 = fac * cI * cJ * exp(-ai * aj_aij * rr_ij) * inv_aij * inv_akl * sinv;
+                            if (ax == 0) g0 = ckcl;
+                            else if (ax == 1) g0 = fac * cicj * inv_aij * inv_akl * sinv;
                             else g0 = wt;
                             real tt[LIJ + 1][LKL + 1];
                             tt[0][0] = g0;
+                            if (ABLATE & 32) {
+#pragma unroll
+                                for (int q = 0; q <= LIJ; q++)
+#pragma unroll
+                                    for (int cc = 0; cc <= LKL; cc++) tt[q][cc] = g0 + c0 * q + cp * cc;
+                            } else {
                             if (LIJ > 0) {
                                 tt[1][0] = c0 * g0;
 #pragma unroll
@@ -485,6 +512,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                     if (q > 0) v += q * b00 * tt[q - 1][cc];
                                     tt[q][cc + 1] = v;
                                 }
+                            }
                             }
                             real* __restrict__ dst = myT + (r * 3 + ax) * NT2;
 #pragma unroll

@@ -1,0 +1,354 @@
+"""DFT numerical integration on MI355X behind the reference's ``_numint`` interface.
+
+Mirrors ``/root/reference/jqc/pyscf/rks.py``: ``generate_rks_kernel`` (:285) -> ``rks_fun`` (:308, the
+incremental ``nr_rks``), ``rho_fun`` (:366), ``vxc_fun`` (:515); ``generate_get_rho`` (:263),
+``generate_nr_rks`` (:270), ``generate_nr_nlc_vxc`` (:661); ``build_grids`` (:100) and the RKS
+``get_veff`` (:180-260); VV10 driver ``vv10nlc`` (``jqc/backend/rks.py:542-715``).
+
+MI355X-first organisation (see joltqc_amd/csrc/dft_kernels.inc): per 256-point block the significant
+shells are found once (cached per grid and cutoff bucket), the block's AOs are evaluated in batches
+into an HBM workspace and contracted with FP64 MFMA (``C = D_bb AO_b`` for the density,
+``V_bb = AO_b X_b^T`` for the potential).  XC functional evaluation itself stays with the caller's
+``ni.eval_xc_eff`` (libxc, third party), exactly as in the reference (:341).
+
+Gap kept explicit: the reference's FP32 window (contributions between cutoff_fp32 and cutoff_fp64
+evaluated in single precision) is evaluated in FP64 here, i.e. at least as accurately.
+"""
+import math
+
+import numpy as np
+
+from ..backend import lib as _lib
+
+__all__ = ["generate_rks_kernel", "generate_get_rho", "generate_nr_rks", "generate_nr_nlc_vxc", "build_grids",
+           "vv10nlc", "patch"]
+
+ao_cutoff = 1e-13                    # reference rks.py:55
+DIM_BY_XC = {"LDA": 1, "GGA": 4, "MGGA": 5}
+NG = 256
+WORKSPACE_BYTES = 6 << 30            # AO workspace per batch (HBM is 288 GB; blocks are batched to this size)
+
+
+def _t(x, dev):
+    import torch
+    if torch.is_tensor(x):
+        return x.to(device=dev, dtype=torch.float64)
+    return torch.as_tensor(np.asarray(x), dtype=torch.float64, device=dev)
+
+
+class _GridCache:
+    """Padded SoA coordinates + per-block shell lists of one grid (identity + cutoff bucket)."""
+
+    def __init__(self):
+        self.key = None
+        self.sparsity = {}
+
+    def coords(self, grids, dev):
+        import torch
+        c = grids.coords
+        key = (id(c), tuple(c.shape))
+        if self.key != key:
+            ct = _t(c, dev)
+            n = ct.shape[0]
+            npad = (-n) % NG
+            if npad:
+                ct = torch.cat([ct, ct[-1:].expand(npad, 3)], dim=0)
+            self.key = key
+            self.ngrids = n
+            self.ngrids_pad = n + npad
+            self.soa = ct.T.contiguous()
+            self.sparsity = {}
+        return self.soa
+
+    def shells(self, layout, soa, log_cutoff):
+        """Per-block shell lists for a cutoff; bucketed downwards (= more shells, safe) and cached."""
+        import torch
+        bucket = math.floor(log_cutoff * 2.0) / 2.0
+        if bucket not in self.sparsity:
+            dev = soa.device
+            L = _lib.lib()
+            nbas = layout.nbasis
+            nblk = self.ngrids_pad // NG
+            shell_list = torch.empty((nblk, nbas), dtype=torch.int16, device=dev)
+            row_of = torch.empty((nblk, nbas), dtype=torch.int32, device=dev)
+            nshl = torch.empty(nblk, dtype=torch.int32, device=dev)
+            nrow = torch.empty(nblk, dtype=torch.int32, device=dev)
+            _lib.check(L.jqc_dft_ao_screen(soa.data_ptr(), self.ngrids_pad, layout.basis_data_fp64["packed"].data_ptr(),
+                                           layout.device_ao_loc().data_ptr(), nbas, float(bucket), shell_list.data_ptr(),
+                                           row_of.data_ptr(), nshl.data_ptr(), nrow.data_ptr(), _lib.stream_ptr()))
+            nrow_h = nrow.cpu().numpy().astype(np.int64)
+            if len(self.sparsity) > 16:
+                self.sparsity.clear()
+            self.sparsity[bucket] = (shell_list, row_of, nshl, nrow, nrow_h)
+        return self.sparsity[bucket]
+
+
+def _batches(nrow_h, ncomp):
+    """Split the blocks into batches whose padded AO rows fit the workspace; yields (blk0, nblk, row_base, rows)."""
+    pad = (nrow_h + 15) // 16 * 16
+    max_rows = max(int(WORKSPACE_BYTES // (ncomp * NG * 8)), int(pad.max()) if pad.size else 16)
+    b0, n = 0, len(pad)
+    while b0 < n:
+        acc, b1 = 0, b0
+        while b1 < n and acc + pad[b1] <= max_rows:
+            acc += pad[b1]
+            b1 += 1
+        base = np.concatenate([[0], np.cumsum(pad[b0:b1])[:-1]]).astype(np.int64)
+        yield b0, b1 - b0, base, max(int(acc), 16)
+        b0 = b1
+
+
+def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
+    import torch
+    layout = basis_layout
+    nao = layout.nao
+    cache = {"dm_prev": 0, "rho_prev": 0, "wv_prev": 0, "vxcmat_prev": 0}
+    gcache = _GridCache()
+    state = {"ws": None, "stats": {}}
+    log_ao_cutoff = math.log(min(ao_cutoff, cutoff_fp32))
+
+    def _workspace(dev, rows, ncomp):
+        need = rows * NG * ncomp
+        if state["ws"] is None or state["ws"].numel() < need:
+            state["ws"] = torch.empty(need, dtype=torch.float64, device=dev)
+        return state["ws"]
+
+    def _run(grids, ncomp_ao, log_cutoff, body):
+        dev = _lib.require_gpu()
+        L = _lib.lib()
+        soa = gcache.coords(grids, dev)
+        shell_list, row_of, nshl, nrow, nrow_h = gcache.shells(layout, soa, log_cutoff)
+        basis = layout.basis_data_fp64["packed"]
+        stream = _lib.stream_ptr()
+        rows_total = 0
+        for blk0, nblk, base, rows in _batches(nrow_h, ncomp_ao):
+            ws = _workspace(dev, rows, ncomp_ao)
+            base_d = torch.from_numpy(base).to(dev)
+            ao_idx = torch.empty(rows, dtype=torch.int32, device=dev)
+            comp_stride = rows * NG
+            _lib.check(L.jqc_dft_eval_ao(soa.data_ptr(), gcache.ngrids_pad, basis.data_ptr(), layout.nbasis, blk0, nblk,
+                                         shell_list.data_ptr(), row_of.data_ptr(), nshl.data_ptr(), nrow.data_ptr(),
+                                         base_d.data_ptr(), ncomp_ao, comp_stride, ws.data_ptr(), ao_idx.data_ptr(),
+                                         stream))
+            body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, stream)
+            rows_total += int(rows)
+        state["stats"]["ao_rows"] = rows_total
+        state["stats"]["blocks"] = len(nrow_h)
+        state["stats"]["nrow_h"] = nrow_h
+
+    def rho_fun(mol, grids, xctype, dm):
+        """rho[ndim, ngrids] (ndim 1/4/5) for a density matrix in the molecule's AO basis
+        (reference rho_fun, rks.py:366-513)."""
+        dev = _lib.require_gpu()
+        xctype = xctype.upper()
+        ndim = DIM_BY_XC[xctype]
+        d = layout.dm_from_mol(_t(dm, dev).reshape(layout.nao_mol, layout.nao_mol))
+        d = (0.5 * (d + d.T)).contiguous()
+        log_dm = math.log(float(d.abs().max().item()) + 1e-200)          # reference :402-405
+        soa = gcache.coords(grids, dev)
+        rho = torch.zeros((ndim, gcache.ngrids_pad), dtype=torch.float64, device=dev)
+
+        def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, stream):
+            _lib.check(L.jqc_dft_rho(blk0, nblk, gcache.ngrids_pad, nrow.data_ptr(), base_d.data_ptr(), comp_stride,
+                                     ws.data_ptr(), ao_idx.data_ptr(), d.data_ptr(), nao, ndim, rho.data_ptr(), stream))
+        _run(grids, 1 if ndim == 1 else 4, log_ao_cutoff - log_dm, body)
+        out = rho[:, :gcache.ngrids]
+        return out[0] if False else out
+
+    def vxc_fun(mol, grids, xctype, wv):
+        """V_xc matrix in the molecule's AO basis from weighted potential wv[ndim, ngrids]
+        (reference vxc_fun, rks.py:515-656)."""
+        dev = _lib.require_gpu()
+        xctype = xctype.upper()
+        ndim = DIM_BY_XC[xctype]
+        soa = gcache.coords(grids, dev)
+        w = _t(wv, dev).reshape(ndim, -1)
+        if w.shape[1] != gcache.ngrids_pad:
+            wp = torch.zeros((ndim, gcache.ngrids_pad), dtype=torch.float64, device=dev)
+            wp[:, :w.shape[1]] = w
+            w = wp
+        w = w.contiguous()
+        ngrids_per_atom = gcache.ngrids / max(getattr(mol, "natm", 1), 1)
+        log_wv_max = math.log((float(w.abs().max().item()) + 1e-300) * ngrids_per_atom)   # reference :548-551
+        vmat = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
+
+        def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, stream):
+            _lib.check(L.jqc_dft_vxc(blk0, nblk, gcache.ngrids_pad, nrow.data_ptr(), base_d.data_ptr(), comp_stride,
+                                     ws.data_ptr(), ao_idx.data_ptr(), w.data_ptr(), ndim, nao, vmat.data_ptr(), stream))
+        _run(grids, 1 if ndim == 1 else 4, log_ao_cutoff - log_wv_max, body)
+        return layout.dm_to_mol(vmat)
+
+    def rks_fun(ni, mol, grids, xc_code, dm):
+        """Incremental nr_rks (reference rks.py:308-364): returns (nelec, excsum, vxcmat)."""
+        dev = _lib.require_gpu()
+        xctype = ni._xc_type(xc_code) if hasattr(ni, "_xc_type") else _xc_type(xc_code)
+        weights = _t(grids.weights, dev)
+        dm_t = _t(dm, dev)
+        rho = cache["rho_prev"] + rho_fun(mol, grids, xctype, dm_t - cache["dm_prev"])
+        exc, vxc = ni.eval_xc_eff(xc_code, rho, deriv=1, xctype=xctype)[:2]
+        exc, vxc = _t(exc, dev), _t(vxc, dev)
+        exc = exc.reshape(-1)
+        den = rho[0] * weights
+        nelec = float(den.sum())
+        excsum = float((den * exc).sum())
+        wv = vxc.reshape(rho.shape[0], -1) * weights
+        vxcmat = cache["vxcmat_prev"] + vxc_fun(mol, grids, xctype, wv - cache["wv_prev"])
+        cache.update(dm_prev=dm_t.clone(), rho_prev=rho, wv_prev=wv, vxcmat_prev=vxcmat.clone())
+        return nelec, excsum, vxcmat
+
+    rho_fun.stats = state["stats"]
+    vxc_fun.stats = state["stats"]
+    return rks_fun, rho_fun, vxc_fun
+
+
+def _xc_type(xc_code):
+    from pyscf.dft import libxc           # only reachable when PySCF exists
+    return libxc.xc_type(xc_code)
+
+
+def generate_get_rho(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
+    _, rho_fun, _ = generate_rks_kernel(basis_layout, cutoff_fp64, cutoff_fp32)
+
+    def get_rho(mol, dm, grids, *args, **kwargs):
+        return rho_fun(mol, grids, "LDA", dm)[0]
+    return get_rho
+
+
+def generate_nr_rks(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
+    rks_fun, _, _ = generate_rks_kernel(basis_layout, cutoff_fp64, cutoff_fp32)
+    return rks_fun
+
+
+# --------------------------------------------------------------------------------------------- VV10
+def vv10nlc(rho, coords, vvrho, vvweight, vvcoords, nlc_pars, dtype=np.float32):
+    """VV10 non-local correlation: exc[ngrids], vxc[2, ngrids] (reference jqc/backend/rks.py:542-715)."""
+    import torch
+    dev = _lib.require_gpu()
+    L = _lib.lib()
+    rho, vvrho = _t(rho, dev), _t(vvrho, dev)
+    coords, vvcoords, vvweight = _t(coords, dev), _t(vvcoords, dev), _t(vvweight, dev)
+    thresh = 1e-10
+    m = rho[0] >= thresh
+    mi = vvrho[0] >= thresh
+    dens, g2 = rho[0][m], (rho[1:4][:, m] ** 2).sum(0)
+    idens, ig2 = vvrho[0][mi], (vvrho[1:4][:, mi] ** 2).sum(0)
+    Bvv, Cvv = nlc_pars
+    Pi43 = 4.0 * math.pi / 3.0
+    Kvv = Bvv * 1.5 * math.pi * ((9.0 * math.pi) ** (-1.0 / 6.0))
+    Beta = ((3.0 / (Bvv * Bvv)) ** 0.75) / 32.0
+    W0p = torch.sqrt(Cvv * (ig2 / idens ** 2) ** 2 + Pi43 * idens)
+    Kp = Kvv * idens ** (1.0 / 6.0)
+    W0tmp = Cvv * (g2 / dens ** 2) ** 2
+    W0 = torch.sqrt(W0tmp + Pi43 * dens)
+    K = Kvv * dens ** (1.0 / 6.0)
+    dKdR = K / 6.0
+    RpW = idens * vvweight[mi]
+
+    def pad(a, n, fill):
+        out = torch.full((n,) + tuple(a.shape[1:]), fill, dtype=torch.float64, device=dev)
+        out[: a.shape[0]] = a
+        return out
+    n_o, n_i = int(dens.numel()), int(idens.numel())
+    no_pad, ni_pad = n_o + (-n_o) % NG, n_i + (-n_i) % NG
+    c_o = pad(coords[m], no_pad, 0.0).T.contiguous()
+    c_i = pad(vvcoords[mi], ni_pad, 1.0e4).T.contiguous()      # padding points far away with zero weight
+    W0_, K_ = pad(W0, no_pad, 1.0), pad(K, no_pad, 1.0)
+    W0p_, Kp_, RpW_ = pad(W0p, ni_pad, 1.0), pad(Kp, ni_pad, 1.0), pad(RpW, ni_pad, 0.0)
+    F = torch.empty(no_pad, dtype=torch.float64, device=dev)
+    U = torch.empty_like(F)
+    W = torch.empty_like(F)
+    if no_pad and ni_pad:
+        _lib.check(L.jqc_vv10(F.data_ptr(), U.data_ptr(), W.data_ptr(), c_i.data_ptr(), c_o.data_ptr(), W0p_.data_ptr(),
+                              W0_.data_ptr(), K_.data_ptr(), Kp_.data_ptr(), RpW_.data_ptr(), ni_pad, no_pad,
+                              int(np.dtype(dtype) == np.float32), _lib.stream_ptr()))
+    F, U, W = F[:n_o], U[:n_o], W[:n_o]
+    dW0dR = (0.5 * Pi43 * dens - 2.0 * W0tmp) / W0
+    dW0dG = W0tmp * dens / (g2 * W0)
+    n = rho.shape[1]
+    exc = torch.zeros(n, dtype=torch.float64, device=dev)
+    vxc = torch.zeros((2, n), dtype=torch.float64, device=dev)
+    exc[m] = Beta + 0.5 * F
+    vxc[0, m] = Beta + F + 1.5 * (U * dKdR + W * dW0dR)
+    vxc[1, m] = 1.5 * W * dW0dG
+    return exc, vxc
+
+
+def transform_vxc_gga(rho, vxc):
+    """(d e/d rho, d e/d sigma) -> weights on (rho, grad rho) for a spin-restricted GGA
+    (what gpu4pyscf's xc_deriv.transform_vxc(rho, vxc, 'GGA', spin=0) returns; reference rks.py:700)."""
+    import torch
+    out = torch.empty_like(rho[:4])
+    out[0] = vxc[0]
+    out[1:4] = 2.0 * vxc[1] * rho[1:4]
+    return out
+
+
+def generate_nr_nlc_vxc(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
+    """Incremental nr_nlc_vxc (reference rks.py:661-714)."""
+    _, rho_fun, vxc_fun = generate_rks_kernel(basis_layout, cutoff_fp64, cutoff_fp32)
+    cache = {"dm_prev": 0, "rho_prev": 0, "wv_prev": 0, "vmat_prev": 0}
+
+    def nr_nlc_vxc(ni, mol, grids, xc_code, dms):
+        dev = _lib.require_gpu()
+        dm_t = _t(dms, dev)
+        rho = cache["rho_prev"] + rho_fun(mol, grids, "GGA", dm_t - cache["dm_prev"])
+        weights, coords = _t(grids.weights, dev), _t(grids.coords, dev)
+        exc, vxc = 0, 0
+        for nlc_pars, fac in ni.nlc_coeff(xc_code):
+            e, v = vv10nlc(rho, coords, rho, weights, coords, nlc_pars)
+            exc = exc + e * fac
+            vxc = vxc + v * fac
+        den = rho[0] * weights
+        nelec = float(den.sum())
+        excsum = float((den * exc).sum())
+        wv = transform_vxc_gga(rho, vxc) * weights
+        vmat = cache["vmat_prev"] + vxc_fun(mol, grids, "GGA", wv - cache["wv_prev"])
+        cache.update(dm_prev=dm_t.clone(), rho_prev=rho, wv_prev=wv, vmat_prev=vmat.clone())
+        return nelec, excsum, vmat
+    return nr_nlc_vxc
+
+
+# --------------------------------------------------------------------------------------------- grids
+GROUP_BOX_SIZE = 3.0      # reference rks.py:56
+
+
+def arg_group_grids(coords, box_size=GROUP_BOX_SIZE):
+    """Order that groups grid points by cubic boxes so that 256-point blocks are spatially compact
+    (reference arg_group_grids, rks.py:71-97)."""
+    c = np.asarray(coords)
+    lo = c.min(axis=0)
+    box = np.floor((c - lo) / box_size).astype(np.int64)
+    nb = box.max(axis=0) + 1
+    key = (box[:, 0] * nb[1] + box[:, 1]) * nb[2] + box[:, 2]
+    return np.argsort(key, kind="stable")
+
+
+def build_grids(grids, mol=None, with_non0tab=False, sort_grids=True, **kwargs):
+    """``grids.build`` replacement (reference rks.py:100-177): generate the grid with the object's own
+    (PySCF/GPU4PySCF) machinery, then pad to a multiple of 256 with zero-weight points and sort by boxes."""
+    orig = getattr(grids, "_jqc_original_build", None)
+    if orig is None:
+        raise RuntimeError("build_grids needs the object's original build method (installed by apply())")
+    orig(mol, with_non0tab=with_non0tab, sort_grids=sort_grids, **kwargs)
+    coords, weights = np.asarray(grids.coords), np.asarray(grids.weights)
+    order = arg_group_grids(coords)
+    coords, weights = coords[order], weights[order]
+    npad = (-coords.shape[0]) % NG
+    if npad:
+        coords = np.vstack([coords, np.repeat(coords[-1:], npad, axis=0)])
+        weights = np.concatenate([weights, np.zeros(npad)])
+    grids.coords, grids.weights = coords, weights
+    return grids
+
+
+def patch(obj, basis_layout, cutoff_fp32, cutoff_fp64, numpy_boundary):
+    """Install the grid-path closures on an RKS object (reference __init__.py:191-206)."""
+    from types import MethodType
+    ni = obj._numint
+    ni.get_rho = generate_get_rho(basis_layout, cutoff_fp32=cutoff_fp32, cutoff_fp64=cutoff_fp64)
+    ni.nr_rks = MethodType(generate_nr_rks(basis_layout, cutoff_fp32=cutoff_fp32, cutoff_fp64=cutoff_fp64), ni)
+    ni.nr_nlc_vxc = MethodType(generate_nr_nlc_vxc(basis_layout, cutoff_fp32=cutoff_fp32, cutoff_fp64=cutoff_fp64), ni)
+    if hasattr(obj, "grids") and hasattr(obj.grids, "build") and not hasattr(obj.grids, "_jqc_original_build"):
+        obj.grids._jqc_original_build = obj.grids.build
+        obj.grids.build = MethodType(build_grids, obj.grids)
+    return obj
