@@ -93,14 +93,6 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
     obj._jqc_basis_layout = basis_layout_jk
     numpy_boundary = not is_device_obj
 
-    if _is(obj, "RKS"):
-        try:
-            from . import rks as _rks
-        except ImportError:
-            _rks = None
-        if _rks is not None:
-            _rks.patch(obj, BasisLayout.from_mol(obj.mol, alignment=1), dft_cutoff_fp32, dft_cutoff_fp64,
-                       numpy_boundary)
 
     if hasattr(obj, "istype") and not obj.istype("DFRHF") and not obj.istype("DFRKS"):
         def _mk(gen):
@@ -116,6 +108,10 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
                 obj.get_k = lambda *a, **k: get_jk(*a, with_j=False, with_k=True, **k)[1]
         if _is(obj, "RHF") and not _is(obj, "RKS"):
             obj.get_veff = MethodType(_jk.generate_get_veff(), obj)
+
+    if _is(obj, "RKS"):                      # after the J/K closures: the RKS get_veff calls them
+        from . import rks as _rks
+        _rks.patch(obj, BasisLayout.from_mol(obj.mol, alignment=1), dft_cutoff_fp32, dft_cutoff_fp64, numpy_boundary)
 
     obj._joltqc_applied = True
     if not hasattr(obj, "_jqc_original_reset") and hasattr(obj, "reset"):

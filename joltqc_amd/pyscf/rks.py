@@ -341,6 +341,79 @@ def build_grids(grids, mol=None, with_non0tab=False, sort_grids=True, **kwargs):
     return grids
 
 
+def tag_array(x, **attrs):
+    """Attach ecoul/exc/vj/vk to the returned potential (role of gpu4pyscf's tag_array, reference rks.py:181,259)."""
+    if isinstance(x, np.ndarray):
+        try:
+            from pyscf.lib import tag_array as _tag
+            return _tag(x, **attrs)
+        except ImportError:
+            class _Tagged(np.ndarray):
+                pass
+            x = x.view(_Tagged)
+    for k, v in attrs.items():
+        setattr(x, k, v)
+    return x
+
+
+def generate_get_veff():
+    """RKS get_veff: XC from the grid path + J (and scaled K for hybrids / range-separated hybrids) from the
+    patched get_j / get_jk / get_k, incremental in the density (same logic as reference rks.py:180-260)."""
+    import torch
+
+    def get_veff(ks, mol=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
+        if mol is None:
+            mol = ks.mol
+        if dm is None:
+            dm = ks.make_rdm1()
+        dev = _lib.require_gpu()
+        if hasattr(ks, "initialize_grids"):
+            ks.initialize_grids(mol, dm)
+        elif getattr(ks.grids, "coords", None) is None:
+            ks.grids.build()
+        dm_t = _t(dm, dev)
+        ground_state = dm_t.ndim == 2
+        ni = ks._numint
+        if hermi == 2:
+            n, exc, vxc = 0, 0, 0
+        else:
+            n, exc, vxc = ni.nr_rks(mol, ks.grids, ks.xc, dm_t)
+            if hasattr(ks, "do_nlc") and ks.do_nlc():
+                xc = ks.xc if ni.libxc.is_nlc(ks.xc) else ks.nlc
+                n, enlc, vnlc = ni.nr_nlc_vxc(mol, ks.nlcgrids, xc, dm_t)
+                exc += enlc
+                vxc = vxc + vnlc
+        is_hybrid = ni.libxc.is_hybrid_xc(ks.xc) if hasattr(ni, "libxc") else False
+        incremental = getattr(ks, "_eri", None) is None and getattr(ks, "direct_scf", True)
+        if not is_hybrid:
+            vk = None
+            if incremental and getattr(vhf_last, "vj", None) is not None:
+                vj = _t(ks.get_j(mol, dm_t - _t(dm_last, dev), hermi), dev) + _t(vhf_last.vj, dev)
+            else:
+                vj = _t(ks.get_j(mol, dm_t, hermi), dev)
+            vxc = vxc + vj
+        else:
+            omega, alpha, hyb = ni.rsh_and_hybrid_coeff(ks.xc, spin=getattr(mol, "spin", 0))
+            last = incremental and getattr(vhf_last, "vk", None) is not None
+            d = dm_t - _t(dm_last, dev) if last else dm_t
+            vj, vk = ks.get_jk(mol, d, hermi)
+            vj, vk = _t(vj, dev), _t(vk, dev) * hyb
+            if abs(omega) > 1e-10:                    # long-range exchange of range-separated hybrids
+                vk = vk + _t(ks.get_k(mol, d, hermi, omega=omega), dev) * (alpha - hyb)
+            if last:
+                vj = vj + _t(vhf_last.vj, dev)
+                vk = vk + _t(vhf_last.vk, dev)
+            vxc = vxc + vj - 0.5 * vk
+            if ground_state:
+                exc -= float((dm_t * vk.T).sum()) * 0.25
+        ecoul = float((dm_t * vj.T).sum()) * 0.5 if ground_state else None
+        if getattr(ks, "_jqc_numpy_boundary", False):
+            vxc, vj = vxc.cpu().numpy(), vj.cpu().numpy()
+            vk = vk.cpu().numpy() if vk is not None else None
+        return tag_array(vxc, ecoul=ecoul, exc=exc, vj=vj, vk=vk)
+    return get_veff
+
+
 def patch(obj, basis_layout, cutoff_fp32, cutoff_fp64, numpy_boundary):
     """Install the grid-path closures on an RKS object (reference __init__.py:191-206)."""
     from types import MethodType
@@ -351,4 +424,6 @@ def patch(obj, basis_layout, cutoff_fp32, cutoff_fp64, numpy_boundary):
     if hasattr(obj, "grids") and hasattr(obj.grids, "build") and not hasattr(obj.grids, "_jqc_original_build"):
         obj.grids._jqc_original_build = obj.grids.build
         obj.grids.build = MethodType(build_grids, obj.grids)
+    obj._jqc_numpy_boundary = numpy_boundary
+    obj.get_veff = MethodType(generate_get_veff(), obj)
     return obj

@@ -113,3 +113,112 @@ class RHF:
         vhf = self._np(self.get_veff(self.mol, dm, dm_last=dm_last, vhf_last=vhf_last, hermi=1))
         self.e_tot = 0.5 * float(np.einsum("ij,ji->", dm, 2 * h + vhf)) + enuc
         return self.e_tot
+
+
+class _LibXCStub:
+    """The two libxc predicates get_veff consults; the stand-in functional is a pure (non-hybrid, non-NLC) one."""
+
+    @staticmethod
+    def is_hybrid_xc(xc):
+        return False
+
+    @staticmethod
+    def is_nlc(xc):
+        return False
+
+
+class SlaterNumInt:
+    """Stand-in for ``pyscf.dft.numint.NumInt`` restricted to Slater (Dirac) exchange, so the RKS boundary can be
+    exercised without libxc:  e_x = -3/4 (3/pi)^(1/3) rho^(1/3),  v_x = 4/3 e_x."""
+    libxc = _LibXCStub()
+    CX = -0.75 * (3.0 / np.pi) ** (1.0 / 3.0)
+
+    def _xc_type(self, xc_code):
+        return "LDA"
+
+    def eval_xc_eff(self, xc_code, rho, deriv=1, xctype="LDA"):
+        r = rho[0].clamp_min(0) if hasattr(rho, "clamp_min") else np.maximum(rho[0], 0)
+        e = self.CX * r ** (1.0 / 3.0)
+        return e.reshape(-1, 1), (4.0 / 3.0 * e).reshape(1, -1)
+
+    def rsh_and_hybrid_coeff(self, xc_code, spin=0):
+        return 0.0, 0.0, 0.0
+
+    def nlc_coeff(self, xc_code):
+        return ()
+
+
+class Grids:
+    def __init__(self, coords, weights):
+        self.coords, self.weights = coords, weights
+
+    def build(self, mol=None, with_non0tab=False, sort_grids=True, **kw):
+        return self
+
+
+class RKS(RHF):
+    """Minimal restricted Kohn-Sham driver with the attribute surface ``apply`` patches on an RKS object
+    (``_numint``, ``grids``, ``xc``, ``get_j/get_k/get_jk``, ``get_veff`` returning a tagged potential)."""
+
+    def __init__(self, mol, hcore, ovlp, grids, xc="slater", numint=None):
+        super().__init__(mol, hcore, ovlp)
+        self.grids = grids
+        self.nlcgrids = grids
+        self.xc = xc
+        self.nlc = ""
+        self._numint = numint or SlaterNumInt()
+        self._eri = None
+
+    def istype(self, name):
+        return name in ("RKS", "RHF", "SCF", "KohnShamDFT")
+
+    def do_nlc(self):
+        return False
+
+    def get_j(self, mol=None, dm=None, hermi=1, **kw):
+        return self.get_jk(mol, dm, hermi, with_k=False, **kw)[0]
+
+    def get_k(self, mol=None, dm=None, hermi=1, **kw):
+        return self.get_jk(mol, dm, hermi, with_j=False, **kw)[1]
+
+    def kernel(self, dm0=None):
+        S, h = np.asarray(self._ovlp), np.asarray(self._hcore)
+        s, U = np.linalg.eigh(S)
+        X = U[:, s > 1e-10] / np.sqrt(s[s > 1e-10])
+        nocc = self.mol.nelectron // 2
+        enuc = self.mol.energy_nuc()
+        _, c = np.linalg.eigh(X.T @ h @ X)
+        c = X @ c
+        dm = 2.0 * c[:, :nocc] @ c[:, :nocc].T if dm0 is None else np.asarray(dm0)
+        dm_last, v_last, e_last = 0, 0, 0.0
+        errs, focks = [], []
+        for it in range(self.max_cycle):
+            veff = self.get_veff(self.mol, dm, dm_last=dm_last, vhf_last=v_last, hermi=1)
+            dm_last, v_last = dm, veff
+            F = h + self._np(veff)
+            e_tot = float(np.einsum("ij,ji->", dm, h)) + float(veff.ecoul) + float(veff.exc) + enuc
+            err = X.T @ (F @ dm @ S - S @ dm @ F) @ X
+            focks.append(F); errs.append(err)
+            focks, errs = focks[-self.diis_space:], errs[-self.diis_space:]
+            if len(errs) > 1:
+                n = len(errs)
+                B = -np.ones((n + 1, n + 1)); B[n, n] = 0
+                for a in range(n):
+                    for b in range(n):
+                        B[a, b] = float(np.vdot(errs[a], errs[b]))
+                rhs = np.zeros(n + 1); rhs[n] = -1
+                try:
+                    w = np.linalg.solve(B, rhs)[:n]
+                    F = sum(wi * Fi for wi, Fi in zip(w, focks))
+                except np.linalg.LinAlgError:
+                    pass
+            e, cc = np.linalg.eigh(X.T @ F @ X)
+            self.mo_energy, self.mo_coeff = e, X @ cc
+            dm = 2.0 * self.mo_coeff[:, :nocc] @ self.mo_coeff[:, :nocc].T
+            self.cycles = it + 1
+            if abs(e_tot - e_last) < self.conv_tol and np.abs(err).max() < 1e-6:
+                self.converged = True
+                break
+            e_last = e_tot
+        self.e_tot = e_tot
+        return e_tot

@@ -121,3 +121,41 @@ def test_incremental_nr_rks_with_slater_exchange():
         v_ref = dft.eval_vxc(lay, grids.coords, 4.0 / 3.0 * cx * rho ** (1.0 / 3.0) * grids.weights, "LDA")
         assert abs(n - n_ref) < 1e-8 * abs(n_ref) and abs(e - e_ref) < 1e-8 * abs(e_ref)
         assert np.abs(v.cpu().numpy() - v_ref).max() < 1e-8 * np.abs(v_ref).max()
+
+
+def test_rks_scf_through_apply_matches_cpu_oracle_scf():
+    """BASELINE config 3 in miniature: apply() on an RKS object (Slater exchange stand-in for libxc), full SCF on
+    the GPU path vs the same SCF driven by the CPU oracle (dense rho / V_xc / J) on the same grid."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from joltqc_amd.pyscf.rks import tag_array
+    from joltqc_amd.scf import RKS, Grids as G, SlaterNumInt
+    from oracle import dense, dft
+    mol = mole.Mole(atom=H2O, basis="def2-svp")
+    lay = BasisLayout.from_mol(mol)
+    S, T, V = dense.int1e_mol(lay, mol)
+    rng = np.random.default_rng(7)
+    at = mol.atom_coords()
+    coords = at[rng.integers(0, 3, 6000)] + rng.normal(0, 1.0, (6000, 3))
+    coords = coords[np.lexsort(coords.T)]
+    weights = np.full(6000, 0.004)
+    mf = jp.apply(RKS(mol, T + V, S, G(coords, weights)))
+    assert mf._joltqc_applied and mf.get_veff.__func__.__name__ == "get_veff"
+    e_gpu = mf.kernel()
+
+    ref = RKS(mol, T + V, S, G(coords, weights))
+    q = dense.canonical_quartets(lay)
+    cx = SlaterNumInt.CX
+
+    def veff_cpu(self, mol_=None, dm=None, dm_last=0, vhf_last=0, hermi=1):
+        rho = np.maximum(dft.eval_rho(lay, coords, dm, "LDA")[0], 0)
+        exc = float((cx * rho ** (4.0 / 3.0) * weights).sum())
+        vxc = dft.eval_vxc(lay, coords, 4.0 / 3.0 * cx * rho ** (1.0 / 3.0) * weights, "LDA")
+        vj, _ = dense.get_jk(lay, dm, 1, with_k=False, quartets=q)
+        return tag_array(vxc + vj, ecoul=0.5 * float(np.einsum("ij,ji->", dm, vj)), exc=exc, vj=vj, vk=None)
+    from types import MethodType
+    ref.get_veff = MethodType(veff_cpu, ref)
+    e_cpu = ref.kernel()
+    assert mf.converged and ref.converged
+    assert abs(e_gpu - e_cpu) < 1e-8, e_gpu - e_cpu
