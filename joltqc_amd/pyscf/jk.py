@@ -226,12 +226,16 @@ class _TileTables:
     Tile = ``tile_width(l)`` consecutive shells of one (l, nprim) group (groups are padded to that
     multiple); plays the role of ``make_tile_pairs`` (reference jk.py:385-431)."""
 
-    def __init__(self, layout, omega):
-        import torch
+    def __init__(self, layout, omega, q_host=None):
+        """``q_host`` (float32 [nbas, nbas] log-Schwarz matrix) makes the tables host-only: used by the CPU tests
+        of the sharding logic; the product path always takes the device matrix."""
         from ..constants import tile_width
-        dev = _lib.require_gpu()
-        self.q_dev = layout.q_matrix(omega)
-        q_host = self.q_dev.cpu().numpy()
+        host_only = q_host is not None
+        if not host_only:
+            import torch
+            dev = _lib.require_gpu()
+            self.q_dev = layout.q_matrix(omega)
+            q_host = self.q_dev.cpu().numpy()
         goff, gkey = layout.group_offset, layout.group_key
         self.offset: Dict[Tuple[int, int], int] = {}
         self.q_host: Dict[Tuple[int, int], np.ndarray] = {}
@@ -259,8 +263,11 @@ class _TileTables:
                 sh_all.append(sh)
                 q_all.append(self.q_host[gi, gj])
                 off += sh.size
+        self.sh_host = np.concatenate(sh_all) if off else np.zeros(1, dtype=np.uint32)
+        if host_only:
+            return
         if off:
-            self.sh = torch.from_numpy(np.concatenate(sh_all).view(np.int32)).to(dev)
+            self.sh = torch.from_numpy(self.sh_host.view(np.int32)).to(dev)
             self.q = torch.from_numpy(np.concatenate(q_all)).to(dev)
         else:
             self.sh = torch.zeros(1, dtype=torch.int32, device=dev)

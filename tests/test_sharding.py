@@ -1,0 +1,107 @@
+"""Multi-GPU path on CPU: the quartet work is dealt to ranks by `build_tile_plan(shard=(rank, world))`; the raw Fock
+contributions are summed with ONE all-reduce.  Here two gloo processes evaluate their shares with the CPU oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import H2O
+
+
+def _layout_and_tables():
+    from joltqc_amd.constants import tile_width
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import jk as jkmod
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import jk as O
+    mol = mole.Mole(atom=H2O, basis="def2-svp")
+    lay = BasisLayout.from_mol(mol, alignment=tile_width)
+    q = np.log(O.schwarz(lay.packed) + 1e-300).astype(np.float32)
+    q[lay.pad_id, :] = -100
+    q[:, lay.pad_id] = -100
+    tt = jkmod._TileTables(lay, 0.0, q_host=q)
+    return mol, lay, q, tt
+
+
+def _plan_quartets(lay, tt, plans, q, log_cut, log_dm):
+    """Canonical quartets covered by a plan, applying the kernel's in-tile predicate (jk_tile.hip screening)."""
+    from joltqc_amd.constants import tile_width
+    nb = lay.nbasis
+    out = set()
+    for ang, (tab, _, _) in plans.items():
+        tw = [tile_width(l) for l in ang]
+        for ij0, nij, kl0, nkl in tab[:, :4]:
+            for pij in tt.sh_host[ij0:ij0 + nij]:
+                for pkl in tt.sh_host[kl0:kl0 + nkl]:
+                    i0, j0, k0, l0 = int(pij) >> 16, int(pij) & 0xffff, int(pkl) >> 16, int(pkl) & 0xffff
+                    for a in range(tw[0]):
+                        for b in range(tw[1]):
+                            for c in range(tw[2]):
+                                for d in range(tw[3]):
+                                    i, j, k, l = i0 + a, j0 + b, k0 + c, l0 + d
+                                    if i >= j and k >= l and i * nb + j >= k * nb + l and q[i, j] + q[k, l] + log_dm > log_cut:
+                                        assert (i, j, k, l) not in out
+                                        out.add((i, j, k, l))
+    return out
+
+
+def test_shards_partition_the_plan():
+    from joltqc_amd.pyscf import jk as jkmod
+    from oracle import dense
+    mol, lay, q, tt = _layout_and_tables()
+    log_cut, log_dm = float(np.log(1e-13)), 0.0
+    full = jkmod.build_tile_plan(lay, tt, log_cut, log_dm, lambda a: True)
+    rows_full = sum(p[0].shape[0] for p in full.values())
+    parts = [jkmod.build_tile_plan(lay, tt, log_cut, log_dm, lambda a: True, shard=(r, 3)) for r in range(3)]
+    assert sum(sum(p[0].shape[0] for p in part.values()) for part in parts) == rows_full
+    qs = [_plan_quartets(lay, tt, part, q, log_cut, log_dm) for part in parts]
+    assert not (qs[0] & qs[1]) and not (qs[0] & qs[2]) and not (qs[1] & qs[2])
+    allq = qs[0] | qs[1] | qs[2]
+    assert allq == _plan_quartets(lay, tt, full, q, log_cut, log_dm)
+    # with these cutoffs nothing of H2O/def2-SVP is screened: the union is every canonical quartet
+    assert allq == {tuple(int(x) for x in t) for t in dense.canonical_quartets(lay)}
+
+
+def _worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    from joltqc_amd.pyscf import jk as jkmod
+    from oracle import jk as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mol, lay, q, tt = _layout_and_tables()
+    log_cut = float(np.log(1e-13))
+    plan = jkmod.build_tile_plan(lay, tt, log_cut, 0.0, lambda a: True, shard=(rank, world))
+    mine = np.array(sorted(_plan_quartets(lay, tt, plan, q, log_cut, 0.0)), dtype=np.uint16).reshape(-1, 4)
+    rng = np.random.default_rng(9)
+    dm = rng.random((lay.nao, lay.nao))
+    dm = dm @ dm.T
+    vj, vk = O.jk_raw(lay.packed, dm, mine)
+    fock = torch.from_numpy(np.stack([vj[0], vk[0]]))
+    dist.all_reduce(fock)                       # the one collective of the path
+    if rank == 0:
+        ret["fock"] = fock.numpy()
+        ret["dm"] = dm
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_equals_single_rank():
+    import torch.multiprocessing as mp
+    from oracle import dense
+    from oracle import jk as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    procs = [mp.get_context("spawn").Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    mol, lay, q, tt = _layout_and_tables()
+    vj, vk = O.jk_raw(lay.packed, ret["dm"], dense.canonical_quartets(lay))
+    assert np.abs(ret["fock"][0] - vj[0]).max() < 1e-11
+    assert np.abs(ret["fock"][1] - vk[0]).max() < 1e-11
