@@ -38,8 +38,12 @@ constexpr int G = 256 / T;
 #ifndef ABLATE
 #define ABLATE 0    // timing-only builds (wrong results): 1 skip phase A, 2 skip phase B, 4 skip contraction, 8 no barriers
 #endif
+#ifndef RYS_LDS_MAX
+#define RYS_LDS_MAX 28672   // stage the class's Chebyshev table in LDS when it is at most this many bytes (nroots <= 5 in f64)
+#endif
 #ifndef MINW
-#define MINW 1      // waves per SIMD the register allocator must leave room for (measured: 1 is fastest)
+#define MINW (TILE_1Q ? 2 : 1)   // waves/SIMD the register allocator leaves room for (measured best: 2 for the
+                                  // lane-per-quartet mode, 1 for the row-lane mode; profiles/r01_*)
 #endif
 constexpr int pick_nch()
 {
@@ -52,10 +56,12 @@ constexpr int CW = NFK / NCH;
 constexpr int E = CW * NFL;
 constexpr int WI = TSI * NFI, WJ = TSJ * NFJ, WK = TSK * NFK, WL = TSL * NFL;
 constexpr int NT2 = (LIJ + 1) * (LKL + 1);
+constexpr int RYS_TAB = (2 * NROOTS + 14) * NROOTS * NCOEF * 2;          // Chebyshev table of this class, in reals
+constexpr bool RYS_IN_LDS = RYS_TAB * (int)sizeof(real) <= RYS_LDS_MAX;
 static_assert(T <= 256 && G >= 1 && NQ <= 256, "tile geometry");
 
 // Rys root `r` only (same tables and branches as rys_roots in jk_common.h)
-__device__ __forceinline__ void rys_root_one(real x, real theta, real omega, const int r, const real* __restrict__ cheb,
+__device__ __forceinline__ void rys_root_one(real x, real theta, real omega, const int r, const real* cheb,
                                              const real* __restrict__ large, real& root, real& weight)
 {
     real tf = 1, stf = 1;
@@ -77,7 +83,7 @@ __device__ __forceinline__ void rys_root_one(real x, real theta, real omega, con
     const int it = (int)(x * real(0.4));
     const real u = (x - real(2.5) * it) * real(0.8) - real(1);
     const real u2 = u + u;
-    const real* __restrict__ c = cheb + (it * NROOTS + r) * (NCOEF * 2);
+    const real* c = cheb + (it * NROOTS + r) * (NCOEF * 2);
     real br1 = 0, br2 = 0, bw1 = 0, bw2 = 0;
 #pragma unroll
     for (int k = NCOEF - 1; k >= 1; k--) {
@@ -134,6 +140,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     // every exp / reciprocal of the pair prefactors is evaluated once per workgroup, not once per quartet
     __shared__ real sBas[(TSI + TSJ + TSK + TSL) * BASIS_STRIDE];
     __shared__ real sPB[TSI * TSJ * 9 * 3], sPK[TSK * TSL * 9 * 3];
+    // Rys Chebyshev table of the class: every lane reads 28 coefficients of ITS OWN x-interval per root, i.e. 64
+    // different cache lines per wave instruction from global memory; from LDS the same gather costs a few cycles
+    __shared__ real sRys[RYS_IN_LDS ? RYS_TAB : 1];
 
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -203,6 +212,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                      : sl < TSI + TSJ + TSK ? ksh0 + sl - TSI - TSJ : lsh0 + sl - TSI - TSJ - TSK;
         sBas[n] = basis[sh * BASIS_STRIDE + w];
     }
+    if (RYS_IN_LDS)
+        for (int n = tid; n < RYS_TAB; n += 256) sRys[n] = rys_cheb[n];
+    const real* cheb_tab = RYS_IN_LDS ? sRys : rys_cheb;
     __syncthreads();
     for (int n = tid; n < (TSI * TSJ + TSK * TSL) * 9; n += 256) {
         const bool bra = n < TSI * TSJ * 9;
@@ -295,10 +307,11 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     const real inv = sinv * sinv;
                     const real theta = aij * akl * inv;
                     const real gy0 = cicj * inv_aij * inv_akl * sinv;
-                    real rw[2 * NROOTS];
-                    rys_roots(rr, theta, omega, rys_cheb, rys_large, rw);
+#pragma clang loop unroll(disable)
                     for (int ir = 0; ir < NROOTS; ir++) {
-                        const real t2 = rw[2 * ir], wt = rw[2 * ir + 1];
+                        // one root at a time: evaluating all roots at once keeps 28 table coefficients per root live
+                        real t2, wt;
+                        rys_root_one(rr, theta, omega, ir, cheb_tab, rys_large, t2, wt);
                         const real rt_aa = t2 * inv;
                         const real rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
                         const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
@@ -325,6 +338,11 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
             }
             const int iA = a * NFI, jA = b * NFJ, kA = c * NFK, lA = d * NFL;
+            if (ABLATE & 4) {
+                real s = 0;
+                for (int n = 0; n < NINT; n++) s += I[n];
+                if (s == real(1.2345)) lds_add(&sJij[0], (double)s);
+            } else {
 #if DO_J
             {
                 real jkl[NFK * NFL], dkl[NFK * NFL];
@@ -395,6 +413,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
             }
 #endif
+            }
         }
 #else
 #pragma unroll
@@ -475,7 +494,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             const real theta = aij * akl * inv;
                             real t2, wt;
                             if (ABLATE & 16) { t2 = real(0.3) + real(0.01) * r; wt = real(0.5); }
-                            else rys_root_one(rr, theta, omega, r, rys_cheb, rys_large, t2, wt);
+                            else rys_root_one(rr, theta, omega, r, cheb_tab, rys_large, t2, wt);
                             const real rt_aa = t2 * inv;
                             const real rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
                             const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);

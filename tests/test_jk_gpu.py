@@ -110,7 +110,6 @@ def test_jk_screening_far_apart_atoms():
     assert np.abs(_np(vj) - rj).max() < 1e-9 and np.abs(_np(vk) - rk).max() < 1e-9
 
 
-@pytest.mark.skip(reason="(gg|gg) needs the tiled kernel; 1q1t would need 400 KB scratch per lane")
 def test_g_functions_class():
     # LMAX = 4 path (reference test_scf.py:90-108 uses def2-QZVPP H2); inline basis with one g shell per atom
     from oracle import dense
