@@ -22,7 +22,7 @@ def _table():
     return {}
 
 
-TILE1Q_MAX_NINT = 108     # above this the one-quartet-per-lane body spills to scratch on gfx950
+TILE1Q_MAX_NINT = int(os.environ.get("JQC_TILE1Q_MAX", "108"))   # above this the lane-per-quartet body spills heavily
 
 
 def nint(ang):
