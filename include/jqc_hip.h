@@ -27,6 +27,11 @@ extern "C" {
 #define JQC_ALGO_1Q1T 0 /* one quartet per lane        (reference jk_1q1t.py / jk/1q1t.cu)  */
 #define JQC_ALGO_TILE 1 /* lane-group per quartet, LDS Fock tiles (replaces jk_1qnt.py / jk/1qnt.cu) */
 #define JQC_ALGO_TILE1Q 2 /* one quartet per lane inside the same LDS tile framework (small classes) */
+#define JQC_ALGO_TILE512 3 /* JQC_ALGO_TILE with 512-thread workgroups: two waves per SIMD on one set of LDS tiles */
+/* Tuning variant of a tiled kernel, OR-ed into the `algo` argument of jqc_gen_jk_kernel (gfx950 scheme table): */
+#define JQC_VARIANT_MINW(n) ((n) << 4) /* waves per SIMD the register allocation leaves room for (0 = kernel default) */
+#define JQC_VARIANT_RYS_L2 (1 << 8)    /* read the Rys table through L2 instead of staging it in LDS */
+#define JQC_VARIANT_ST1 (1 << 9)       /* single-buffered TRR array (less LDS, one more barrier per primitive combination) */
 
 const char* jqc_last_error(void);
 const char* jqc_version(void);
@@ -53,19 +58,26 @@ int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, do
                   double omega, const void* quartets_d, const uint32_t* ntasks_d, int64_t ntasks_max,
                   int qstride, int n_dm, void* stream);
 
-/* Launch of a tiled J/K kernel (JQC_ALGO_TILE).  No quartet queue: one workgroup per (bra tile pair, ket tile
- * pair); screening (same predicate as jqc_screen_jk_tasks) happens inside the workgroup.
- *   tasks_d     int32[ntasks][8] = {ij0, nij, kl0, nkl, 0, blk0, cnt, 0}: rectangle of tile-pair lists, nij*nkl blocks
- *   tpair_sh_d  uint32[...] = first shell of tile i <<16 | first shell of tile j; tpair_q_d = max log-Schwarz of the pair
+/* Launch of a tiled J/K kernel (JQC_ALGO_TILE / JQC_ALGO_TILE1Q).  No quartet queue: one workgroup per (bra tile
+ * pair, chunk of consecutive ket tile pairs); screening (same predicate as jqc_screen_jk_tasks) happens inside the
+ * workgroup.
+ *   tasks_d     int32[ntasks][8] = {ij0, nij, kl0, nkl, nchunk, blk0, cnt, kchunk}: rectangle of the two tile-pair
+ *               lists; the row owns nij*nchunk workgroups starting at blk0, nchunk = ceil(nkl / kchunk)
+ *   nblocks     total workgroups of the launch
+ *   tpair_sh_d  uint32[...] = first shell of tile i <<16 | first shell of tile j; tpair_q_d = max log-Schwarz of the
+ *               pair, each list sorted descending (a workgroup stops at the first ket pair below the cutoff)
  *   q_cond_d, log_dm_d  float[nbas*nbas];  processes quartets with cut_lo < q_ij+q_kl+d_large <= cut_hi
  *   counter_d   optional uint64[]: the number of quartets evaluated by a workgroup is added to counter_d[cnt]
  *               (per-class dispatch counters = the "ERI quartets/s" metric, reference jk.py:288-330)
+ *   blk_index_d int32[nblocks/256 + 1]: task row of every 256th workgroup (coarse index of the blk0 column)
+ *   tpair_ao_d  uint32[...] = first AO of tile i <<16 | first AO of tile j (same indexing as tpair_sh_d; nao < 65536)
  * Tile widths are fixed per angular momentum: 4 shells for l<=2, 2 for l=3, 1 for l=4; every (l,nprim) group of
  * the shell table must be padded to that multiple (BasisLayout.from_mol(alignment=tile_width)). */
 int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_d, double* vj_d, double* vk_d,
                        double omega, const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* tpair_sh_d,
                        const float* tpair_q_d, const float* q_cond_d, const float* log_dm_d, int nbas, float cut_lo,
-                       float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, void* stream);
+                       float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, const int32_t* blk_index_d,
+                       const uint32_t* tpair_ao_d, void* stream);
 
 /* Screening + queue generation (replaces screen_jk_tasks, jqc/backend/jk/screen_jk_tasks.cu:75-340).
  * One launch handles a whole chunk of "screen tasks"; task t covers the rectangle

@@ -23,6 +23,7 @@ def _table():
 
 
 TILE1Q_MAX_NINT = int(os.environ.get("JQC_TILE1Q_MAX", "108"))   # above this the lane-per-quartet body spills heavily
+TILE1Q_FORCE_MAX = 200    # largest integral block the lane-per-quartet mode is ever tried on (512 VGPRs at 1 wave/SIMD)
 
 
 def nint(ang):
@@ -38,14 +39,23 @@ def class_key(ang):
 
 
 def select_algo(ang, fp32=False):
+    """Algorithm + tuning variant of class ``ang`` (low 4 bits: lib.ALGO_*, bits 4-7: waves per SIMD, bit 8: Rys table
+    through L2, bit 9: single TRR buffer; include/jqc_hip.h JQC_VARIANT_*)."""
     t = _table().get("fp32" if fp32 else "fp64", {})
     forced = os.environ.get("JQC_JK_ALGO")
     if forced:
         f = forced.lower()
+        if f.startswith("v"):                         # raw variant code, e.g. v289; lane-per-quartet only where it fits
+            v = int(f[1:])
+            if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > TILE1Q_FORCE_MAX:
+                return _lib.ALGO_TILE
+            return v
         if f in ("0", "1q1t"):
             return _lib.ALGO_1Q1T
         if f in ("2", "tile1q"):
             return _lib.ALGO_TILE1Q if nint(ang) <= TILE1Q_MAX_NINT else _lib.ALGO_TILE
+        if f in ("3", "tile512"):
+            return _lib.ALGO_TILE512
         return _lib.ALGO_TILE
     v = t.get(class_key(ang))
     if v is None:

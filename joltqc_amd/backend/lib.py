@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(CSRC, "libjqc_hip.so")
 ALGO_1Q1T = 0
 ALGO_TILE = 1
 ALGO_TILE1Q = 2
+ALGO_TILE512 = 3
 
 _lib = None
 _lock = threading.Lock()
@@ -60,7 +61,7 @@ def lib():
         L.jqc_gen_jk_kernel.argtypes = [i32] * 10
         L.jqc_jk_launch.argtypes = [i32, i32, vp, vp, vp, vp, f64, vp, vp, i64, i32, i32, vp]
         L.jqc_jk_tile_launch.argtypes = [i32, i32, vp, vp, vp, vp, f64, vp, i32, i32, vp, vp, vp, vp, i32, f32, f32, f32,
-                                         i32, vp, vp]
+                                         i32, vp, vp, vp, vp]
         L.jqc_screen_jk_tasks.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp]
         L.jqc_shell_block_max.argtypes = [vp, i32, i32, vp, i32, vp, vp]
         L.jqc_schwarz.argtypes = [i32, i32, vp, vp, i32, f64, vp, vp]

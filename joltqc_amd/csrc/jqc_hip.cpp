@@ -277,23 +277,27 @@ int jqc_set_rys_tables(const double* blob, size_t n)
     return 0;
 }
 
-int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int rys_lr, int fp32, int algo,
+int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int rys_lr, int fp32, int algo_variant,
                       int compile_only)
 {
     std::lock_guard<std::mutex> lk_(g_mu);
+    // algo_variant: low 4 bits = JQC_ALGO_*, the rest = tuning variant of the tiled kernels (JQC_VARIANT_*)
+    const int algo = algo_variant & 0xf;
+    const int v_minw = (algo_variant >> 4) & 0xf;
+    const int v_rys_l2 = (algo_variant >> 8) & 1, v_st1 = (algo_variant >> 9) & 1;
     if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
     if (!do_j && !do_k) return fail(-1, "need do_j or do_k");
     char key[128];
-    snprintf(key, sizeof key, "jk%d_%d%d%d%d_j%dk%d_lr%d_%s", algo, li, lj, lk, ll, do_j, do_k, rys_lr,
+    snprintf(key, sizeof key, "jk%d_%d%d%d%d_j%dk%d_lr%d_%s", algo_variant, li, lj, lk, ll, do_j, do_k, rys_lr,
              fp32 ? "f32" : "f64");
     auto it = g_by_key.find(key);
     if (it != g_by_key.end() && (compile_only || g_kernels[it->second].fn)) return it->second;
-    const bool tiled = algo == JQC_ALGO_TILE || algo == JQC_ALGO_TILE1Q;
+    const bool tiled = algo == JQC_ALGO_TILE || algo == JQC_ALGO_TILE1Q || algo == JQC_ALGO_TILE512;
     const char* src = tiled ? "jk_tile.hip" : "jk_1q1t.hip";
     // per-class entry-point name so that rocprofv3 --stats lists every class separately
     char entry[64];
-    snprintf(entry, sizeof entry, "%s_%d%d%d%d%s", tiled ? (algo == JQC_ALGO_TILE1Q ? "jk_tile1q" : "jk_tile") : "jk_1q1t",
+    snprintf(entry, sizeof entry, "%s_%d%d%d%d%s", tiled ? (algo == JQC_ALGO_TILE1Q ? "jk_tile1q" : algo == JQC_ALGO_TILE512 ? "jk_tile512" : "jk_tile") : "jk_1q1t",
              li, lj, lk, ll, fp32 ? "_f32" : "");
     const std::string out = g_cache_dir + "/" + key + "_" + g_src_tag + ".hsaco";
     if (!file_exists(out)) {
@@ -302,7 +306,11 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
                                       "-DDO_J=" + std::to_string(do_j), "-DDO_K=" + std::to_string(do_k),
                                       "-DRYS_LR=" + std::to_string(rys_lr), "-DFP32=" + std::to_string(fp32),
                                       "-DTILE_1Q=" + std::to_string(algo == JQC_ALGO_TILE1Q ? 1 : 0),
+                                      "-DTBLOCK=" + std::to_string(algo == JQC_ALGO_TILE512 ? 512 : 256),
                                       std::string("-DKNAME=") + entry};
+        if (v_minw) d.push_back("-DMINW=" + std::to_string(v_minw));
+        if (v_rys_l2) d.push_back("-DRYS_LDS_MAX=0");
+        if (v_st1) d.push_back("-DST_LDS_MAX=0");
         int rc = compile_to(src, d, out);
         if (rc) return rc;
     }
@@ -352,11 +360,13 @@ int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, do
 int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_d, double* vj_d, double* vk_d,
                        double omega, const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* tpair_sh_d,
                        const float* tpair_q_d, const float* q_cond_d, const float* log_dm_d, int nbas, float cut_lo,
-                       float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, void* stream)
+                       float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, const int32_t* blk_index_d,
+                       const uint32_t* tpair_ao_d, void* stream)
 {
     if (handle < 0 || handle >= (int)g_kernels.size() || !g_kernels[handle].fn)
         return fail(-1, "invalid kernel handle %d", handle);
-    if (g_kernels[handle].algo != JQC_ALGO_TILE && g_kernels[handle].algo != JQC_ALGO_TILE1Q)
+    if (g_kernels[handle].algo != JQC_ALGO_TILE && g_kernels[handle].algo != JQC_ALGO_TILE1Q &&
+        g_kernels[handle].algo != JQC_ALGO_TILE512)
         return fail(-1, "handle %d is not a tile kernel", handle);
     if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
     if (ntasks <= 0 || nblocks <= 0) return 0;
@@ -367,8 +377,9 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
     const void* large = k.fp32 ? (const void*)rys_large32(n) : (const void*)rys_large64(n);
     void* args[] = {&nao, &basis_d, &dm_d, &vj_d, &vk_d, k.fp32 ? (void*)&omega_f : (void*)&omega, &tasks_d, &ntasks,
                     &tpair_sh_d, &tpair_q_d, &q_cond_d, &log_dm_d, &nbas, &cut_lo, &cut_hi, &log_max_dm, &n_dm,
-                    &cheb, &large, &counter_d};
-    HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)nblocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+                    &cheb, &large, &counter_d, &blk_index_d, &tpair_ao_d};
+    const unsigned threads = k.algo == JQC_ALGO_TILE512 ? 512 : 256;
+    HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)nblocks, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, args, nullptr));
     return 0;
 }
 

@@ -264,8 +264,12 @@ class _TileTables:
                 q_all.append(self.q_host[gi, gj])
                 off += sh.size
         self.sh_host = np.concatenate(sh_all) if off else np.zeros(1, dtype=np.uint32)
+        assert layout.nao < 65536, "tile-pair AO offsets are packed into 16 bits"
+        aol = np.asarray(layout.ao_loc).astype(np.uint32)
+        self.ao_host = ((aol[self.sh_host >> np.uint32(16)] << np.uint32(16)) | aol[self.sh_host & np.uint32(0xffff)]).astype(np.uint32)
         if host_only:
             return
+        self.ao = torch.from_numpy(self.ao_host.view(np.int32)).to(dev)
         if off:
             self.sh = torch.from_numpy(self.sh_host.view(np.int32)).to(dev)
             self.q = torch.from_numpy(np.concatenate(q_all)).to(dev)
@@ -314,14 +318,28 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
                                      (int(gkey[gi, 1]), int(gkey[gj, 1]), int(gkey[gk, 1]), int(gkey[gl, 1]))))
     plans = {}
     for ang, rows in per_class.items():
+        if not rows:
+            continue
+        # ket chunk: consecutive ket tile pairs walked by ONE workgroup (bra-side staging amortised); as long as
+        # the class still fills the chip (>= TARGET_WGS workgroups) the chunks grow up to KCHUNK_MAX
+        nblk1 = sum(r[1] * r[3] for r in rows)
+        kchunk = int(min(KCHUNK_MAX, max(1, nblk1 // TARGET_WGS)))
         tab = np.zeros((len(rows), 8), dtype=np.int32)
         blk = 0
         for n, (ij0, nij, kl0, nkl, _) in enumerate(rows):
-            tab[n, :6] = (ij0, nij, kl0, nkl, 0, blk)
-            blk += nij * nkl
+            nchunk = -(-nkl // kchunk)
+            tab[n] = (ij0, nij, kl0, nkl, nchunk, blk, 0, kchunk)
+            blk += nij * nchunk
             assert blk < 2 ** 31
-        plans[ang] = (tab, blk, [r[4] for r in rows])
+        # coarse index: task row of every 256th workgroup (the kernel probes forward from there)
+        starts = tab[:, 5].astype(np.int64)
+        index = (np.searchsorted(starts, np.arange(0, blk + 256, 256), side="right") - 1).astype(np.int32)
+        plans[ang] = (tab, blk, [r[4] for r in rows], index)
     return plans
+
+
+KCHUNK_MAX = int(__import__('os').environ.get('JQC_KCHUNK_MAX', '16'))
+TARGET_WGS = int(__import__('os').environ.get('JQC_TARGET_WGS', '4096'))
 
 
 def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard=None):
@@ -381,7 +399,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
         vk_p = vk.data_ptr() if with_k else None
         b64 = layout.basis_data_fp64["packed"]
         b32 = layout.basis_data_fp32["packed"] if mixed else None
-        is_tile = lambda ang: _router.select_algo(ang) in (_lib.ALGO_TILE, _lib.ALGO_TILE1Q)
+        is_tile = lambda ang: (_router.select_algo(ang) & 0xf) in (_lib.ALGO_TILE, _lib.ALGO_TILE1Q, _lib.ALGO_TILE512)
         n_launch = 0
         counter_bufs = []
         tile_counts = None
@@ -404,7 +422,13 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     order = sorted(tplans, key=lambda a: -cost[a])              # longest first over the streams
                     tabs = np.concatenate([tplans[a][0] for a in order])
                     tabs[:, 6] = np.arange(tabs.shape[0])                       # counter slot of every task row
+                    index = np.concatenate([tplans[a][3] for a in order])
+                    ioff, pos = {}, 0
+                    for a in order:
+                        ioff[a] = pos
+                        pos += tplans[a][3].size
                     entry = {"order": order, "tabs_d": torch.from_numpy(tabs).to(dev), "nrows": tabs.shape[0],
+                             "index_d": torch.from_numpy(index).to(dev), "index_off": ioff,
                              "plans": tplans, "row_meta": [(a, npr) for a in order for npr in tplans[a][2]]}
                 if len(state["plan_cache"]) > 64:
                     state["plan_cache"].clear()
@@ -412,7 +436,10 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
             entry = state["plan_cache"][pkey]
             if entry is not None:
                 order, tabs_d, tplans = entry["order"], entry["tabs_d"], entry["plans"]
-                tile_counts = torch.zeros((2, entry["nrows"]), dtype=torch.int64, device=dev)
+                # 32 leading slots: diagnostic cycle stamps of -DSTAMPS=1 kernel builds (tools/stamps_profile.py)
+                counts_buf = torch.zeros(32 + 2 * entry["nrows"], dtype=torch.int64, device=dev)
+                tile_counts = counts_buf[32:].view(2, entry["nrows"])
+                state["stats"]["stamps"] = counts_buf[:32]
                 if state["streams"] is None or len(state["streams"]) != state["nstreams"]:
                     state["streams"] = [torch.cuda.Stream(device=dev) for _ in range(state["nstreams"])]
                 side = state["streams"]
@@ -422,8 +449,13 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                 for st_ in side:
                     st_.wait_event(ev)
                 row = 0
+                only = __import__('os').environ.get("JQC_ONLY_CLASS")
                 for n, ang in enumerate(order):
-                    tab, nblk, _ = tplans[ang]
+                    tab, nblk, _, _ = tplans[ang]
+                    if only and "%d%d%d%d" % tuple(ang) not in only.split(","):
+                        row += tab.shape[0]
+                        continue
+                    idx_p = entry["index_d"].data_ptr() + entry["index_off"][ang] * 4
                     sid = side[n % len(side)]
                     sp = sid.cuda_stream
                     h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False,
@@ -436,7 +468,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                                                     tabs_d.data_ptr() + row * 32, tab.shape[0], nblk, tt.sh.data_ptr(),
                                                     tt.q.data_ptr(), tt.q_dev.data_ptr(), log_dm_cond.data_ptr(), nbas,
                                                     log_cutoff_fp64 if mixed else log_cutoff_fp32, INF, log_max_dm, n_dm,
-                                                    tile_counts[0].data_ptr(), sp))
+                                                    tile_counts[0].data_ptr(), idx_p, tt.ao.data_ptr(), sp))
                     if probing:
                         ev1.record(sid)
                         state["stats"].setdefault("probe_events", []).append((ev0, ev1))
@@ -449,7 +481,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                                                         tabs_d.data_ptr() + row * 32, tab.shape[0], nblk,
                                                         tt.sh.data_ptr(), tt.q.data_ptr(), tt.q_dev.data_ptr(),
                                                         log_dm_cond.data_ptr(), nbas, log_cutoff_fp32, log_cutoff_fp64,
-                                                        log_max_dm, n_dm, tile_counts[1].data_ptr(), sp))
+                                                        log_max_dm, n_dm, tile_counts[1].data_ptr(), idx_p, tt.ao.data_ptr(), sp))
                         n_launch += 1
                     row += tab.shape[0]
                 for st_ in side:

@@ -29,7 +29,7 @@ def _plan_quartets(lay, tt, plans, q, log_cut, log_dm):
     from joltqc_amd.constants import tile_width
     nb = lay.nbasis
     out = set()
-    for ang, (tab, _, _) in plans.items():
+    for ang, (tab, *_rest) in plans.items():
         tw = [tile_width(l) for l in ang]
         for ij0, nij, kl0, nkl in tab[:, :4]:
             for pij in tt.sh_host[ij0:ij0 + nij]:

@@ -1,0 +1,136 @@
+"""Per-class autotuner of the tiled J/K kernels for gfx950 (role of the reference's
+jqc/backend/data/generate_fragment.py + optimal_scheme_<GPU>_fp64.json).
+
+  build   (CPU, here)  : compile every candidate variant of every class into joltqc_amd/csrc/kcache_tune
+  run     (GPU box)    : time every class under every variant on a workload -> gpurun_out/autotune_<workload>.json
+  merge   (CPU)        : best variant per class -> joltqc_amd/data/gfx950_scheme.json
+
+usage: python tools/autotune.py build | run [workload] | merge <json> [<json2> ...]
+"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CACHE = os.path.join(ROOT, "joltqc_amd", "csrc", "kcache_tune")
+AVAIL = os.path.join(CACHE, "available.json")
+os.environ["JQC_KERNEL_CACHE"] = CACHE
+
+MINW = lambda n: n << 4
+RYS_L2, ST1 = 1 << 8, 1 << 9
+CANDIDATES = [2 | MINW(1), 2 | MINW(2), 2 | MINW(3),
+              1 | MINW(1), 1 | MINW(2), 1 | MINW(1) | RYS_L2, 1 | MINW(2) | RYS_L2, 1 | MINW(2) | RYS_L2 | ST1,
+              1 | MINW(3) | RYS_L2 | ST1, 3, 3 | RYS_L2]
+MAX_1Q = 200
+
+
+def nint(ang):
+    n = 1
+    for l in ang:
+        n *= (l + 1) * (l + 2) // 2
+    return n
+
+
+def classes(lmax=3):
+    return [(a, b, c, d) for a in range(lmax + 1) for b in range(a + 1) for c in range(a + 1) for d in range(c + 1)]
+
+
+def _compile(job):
+    from joltqc_amd.backend import lib as L
+    ang, v = job
+    try:
+        L.gen_jk_kernel(ang, 1, 1, 0, 0, v, compile_only=True)
+        return (ang, v, True)
+    except Exception:  # noqa: BLE001  (LDS overflow of a variant is an expected outcome)
+        return (ang, v, False)
+
+
+def build():
+    from multiprocessing import get_context
+    from joltqc_amd.backend import lib as L
+    L.lib()
+    jobs = [(ang, v) for ang in classes() for v in CANDIDATES if (v & 0xf) != 2 or nint(ang) <= MAX_1Q]
+    with get_context("spawn").Pool(8) as pool:
+        res = list(pool.imap_unordered(_compile, jobs, chunksize=1))
+    ok = sorted(["%d%d%d%d:%d" % (*a, v) for a, v, good in res if good])
+    json.dump(ok, open(AVAIL, "w"))
+    print(f"{len(ok)} of {len(jobs)} variants built")
+
+
+def run(workload):
+    os.environ["JQC_STREAMS"] = "1"
+    import numpy as np, torch
+    from bench import load_workload
+    from joltqc_amd.backend import jk as router
+    from joltqc_amd.constants import tile_width
+    from joltqc_amd.pyscf import jk as jkmod
+    from joltqc_amd.pyscf.basis import BasisLayout
+    avail = set(json.load(open(AVAIL)))
+    mol, name = load_workload(workload)
+    lay = BasisLayout.from_mol(mol, alignment=tile_width)
+    np.random.seed(9)
+    dm = np.random.rand(mol.nao, mol.nao); dm = torch.from_numpy(dm @ dm.T).cuda()
+    out = {}
+    state = {"v": None}
+    default = router.select_algo
+
+    def forced(ang, fp32=False):
+        v = state["v"]
+        return v if "%d%d%d%d:%d" % (*ang, v) in avail else -1
+    for v in CANDIDATES:
+        state["v"] = v
+        # classes the variant does not exist for are skipped (select -> untimed default kernel)
+        router.select_algo = lambda ang, fp32=False: (forced(ang) if forced(ang) >= 0 else default(ang, fp32))
+        g = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
+        g(mol, dm, hermi=1)
+        torch.cuda.synchronize()
+        g.set_probe("all")
+        for _ in range(2):
+            g(mol, dm, hermi=1)
+        torch.cuda.synchronize()
+        tm = {}
+        for ang, (e0, e1) in zip(g.stats["probe_classes"], g.stats["probe_events"]):
+            if forced(ang) >= 0:
+                key = "%d%d%d%d" % tuple(ang)
+                tm[key] = min(tm.get(key, 1e30), e0.elapsed_time(e1))
+        out[str(v)] = tm
+        print(f"variant {v:#x}: {len(tm)} classes, sum {sum(tm.values()):.1f} ms", flush=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(out, open(f"gpurun_out/autotune_{workload}.json", "w"))
+
+
+def merge(files):
+    """Best variant per class; the first file decides, later files only fill classes the first lacks."""
+    best = {}
+    for f in files:
+        data = json.load(open(f))
+        per = {}
+        for v, tm in data.items():
+            for key, ms in tm.items():
+                if key not in per or ms < per[key][1]:
+                    per[key] = (int(v), ms)
+        for key, (v, ms) in per.items():
+            best.setdefault(key, v)
+    path = os.path.join(ROOT, "joltqc_amd", "data", "gfx950_scheme.json")
+    old = json.load(open(path))
+    for prec in ("fp64", "fp32"):
+        for ang in classes(4):
+            key = str(1000 * ang[0] + 100 * ang[1] + 10 * ang[2] + ang[3])
+            k4 = "%d%d%d%d" % ang
+            if k4 in best:
+                old[prec][key] = best[k4]
+    old["_comment"] = ("gfx950 (MI355X) scheme table of the J/K kernels, measured per class by tools/autotune.py on a 112-atom "
+                       "CHNO molecule / def2-TZVPP. Value = algorithm | variant bits (include/jqc_hip.h): low 4 bits 1 = tiled "
+                       "row-lane kernel, 2 = tiled one-quartet-per-lane kernel, 3 = row-lane with 512-thread workgroups; bits 4-7 "
+                       "waves per SIMD; bit 8 Rys table through L2; bit 9 single TRR buffer. g classes (not measured) keep rule-based "
+                       "entries. Role of the reference's optimal_scheme_<GPU>_fp64.json (jqc/backend/data).")
+    json.dump(old, open(path, "w"), indent=0)
+    print("wrote", path, {k: hex(v) for k, v in sorted(best.items())})
+
+
+if __name__ == "__main__":
+    cmd = sys.argv[1]
+    if cmd == "build":
+        build()
+    elif cmd == "run":
+        run(sys.argv[2] if len(sys.argv) > 2 else "0112-elongated-nitrogenous")
+    else:
+        merge(sys.argv[2:])
