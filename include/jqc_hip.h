@@ -42,6 +42,10 @@ const char* jqc_source_tag(void);
  * the gfx950 code objects (one .hsaco per class/variant; replaces CuPy's cubin cache, examples/04). */
 int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir);
 
+/* Shells per tile edge of the tiled J/K kernels for l = 0..4 (default 8,4,4,2,1).  Must match the padding of the
+ * shell table (BasisLayout.from_mol(alignment=tile_width)); part of the code-object cache key. */
+int jqc_set_tile_widths(const int* widths5);
+
 /* Upload the packed Rys tables (layout: joltqc_amd/backend/rys.py) to the current device. */
 int jqc_set_rys_tables(const double* blob_host, size_t ndoubles);
 
@@ -71,13 +75,16 @@ int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, do
  *               (per-class dispatch counters = the "ERI quartets/s" metric, reference jk.py:288-330)
  *   blk_index_d int32[nblocks/256 + 1]: task row of every 256th workgroup (coarse index of the blk0 column)
  *   tpair_ao_d  uint32[...] = first AO of tile i <<16 | first AO of tile j (same indexing as tpair_sh_d; nao < 65536)
- * Tile widths are fixed per angular momentum: 4 shells for l<=2, 2 for l=3, 1 for l=4; every (l,nprim) group of
- * the shell table must be padded to that multiple (BasisLayout.from_mol(alignment=tile_width)). */
+ *   tpair_pp_d  uint32[...] = offset (units of 27 reals) of the tile pair's block in pair_tab_d, the primitive-pair
+ *               prefactor table built by jqc_pair_table (real = double, or float for fp32 kernels)
+ * Tile widths per angular momentum: jqc_set_tile_widths (default 8 shells for s, 4 for p and d, 2 for f, 1 for g);
+ * every (l,nprim) group of the shell table must be padded to that multiple
+ * (BasisLayout.from_mol(alignment=tile_width)). */
 int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_d, double* vj_d, double* vk_d,
                        double omega, const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* tpair_sh_d,
                        const float* tpair_q_d, const float* q_cond_d, const float* log_dm_d, int nbas, float cut_lo,
                        float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, const int32_t* blk_index_d,
-                       const uint32_t* tpair_ao_d, void* stream);
+                       const uint32_t* tpair_ao_d, const uint32_t* tpair_pp_d, const void* pair_tab_d, void* stream);
 
 /* Screening + queue generation (replaces screen_jk_tasks, jqc/backend/jk/screen_jk_tasks.cu:75-340).
  * One launch handles a whole chunk of "screen tasks"; task t covers the rectangle
@@ -99,6 +106,12 @@ int jqc_screen_jk_tasks(const int32_t* tasks_d, int ntasks, int nblocks, const u
  * over shell blocks given by ao_loc_d int32[nbas+1]; M is double[n_dm,nao,nao]; out float[nbas*nbas]. */
 int jqc_shell_block_max(const double* mat_d, int n_dm, int nao, const int32_t* ao_loc_d, int nbas,
                         float* out_d, void* stream);
+
+/* Primitive-pair prefactor table of the tile-pair lists (once per geometry; role of the reference's cached K_ab,
+ * jqc/backend/jk/1q1t.cu:146-171).  For tile pair t (widths wi<<16|wj in tpair_wij_d) the block
+ * out_d[pp_off_d[t]*27 ...] holds {c_a c_b K_ab, 1/(a+b), a+b} at ((a*wj + b)*9 + p1*3 + p2)*3. */
+int jqc_pair_table(const double* basis_d, const uint32_t* tpair_sh_d, const uint32_t* tpair_wij_d,
+                   const uint32_t* pp_off_d, int npairs, double* out_d, void* stream);
 
 /* Schwarz bounds on device (replaces the libcvhf call in compute_q_matrix, jqc/pyscf/basis.py:840-867):
  * for each listed pair p = (ish<<16|jsh) with l(ish)=li, l(jsh)=lj:  out[p] = sqrt(max_ab |(ab|ab)|). */

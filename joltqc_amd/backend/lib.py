@@ -61,7 +61,8 @@ def lib():
         L.jqc_gen_jk_kernel.argtypes = [i32] * 10
         L.jqc_jk_launch.argtypes = [i32, i32, vp, vp, vp, vp, f64, vp, vp, i64, i32, i32, vp]
         L.jqc_jk_tile_launch.argtypes = [i32, i32, vp, vp, vp, vp, f64, vp, i32, i32, vp, vp, vp, vp, i32, f32, f32, f32,
-                                         i32, vp, vp, vp, vp]
+                                         i32, vp, vp, vp, vp, vp, vp]
+        L.jqc_pair_table.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L.jqc_screen_jk_tasks.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp]
         L.jqc_shell_block_max.argtypes = [vp, i32, i32, vp, i32, vp, vp]
         L.jqc_schwarz.argtypes = [i32, i32, vp, vp, i32, f64, vp, vp]
@@ -70,6 +71,10 @@ def lib():
         L.jqc_dft_rho.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp]
         L.jqc_dft_vxc.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp]
         L.jqc_vv10.argtypes = [vp] * 10 + [i32, i32, i32, vp]
+        from ..constants import TILE_WIDTHS
+        L.jqc_set_tile_widths.argtypes = [c.POINTER(c.c_int)]
+        if L.jqc_set_tile_widths((c.c_int * 5)(*TILE_WIDTHS)) < 0:
+            raise RuntimeError("libjqc_hip: " + L.jqc_last_error().decode())
         os.makedirs(KERNEL_CACHE, exist_ok=True)
         L.jqc_set_kernel_dirs(KERNEL_SRC.encode(), KERNEL_CACHE.encode())
         _lib = L

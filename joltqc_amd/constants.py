@@ -11,9 +11,17 @@ SLOT_ANG = 11
 
 
 
+import os as _os
+
+# shells per tile edge of the tiled J/K kernels for l = 0..4 (joltqc_amd/csrc/kernels/jk_tile.hip: ts_of; handed to the
+# library with jqc_set_tile_widths).  s tiles are wider: the s-containing classes have the cheapest quartets, so the
+# per-tile-pair staging and Fock flush must be shared by more of them.
+TILE_WIDTHS = tuple(int(x) for x in _os.environ.get("JQC_TILE_WIDTHS", "8,4,4,2,1").split(","))
+
+
 def tile_width(l: int) -> int:
-    """Shells per tile edge of the tiled J/K kernels (joltqc_amd/csrc/kernels/jk_tile.hip: ts_of)."""
-    return 4 if l <= 2 else (2 if l == 3 else 1)
+    """Shells per tile edge of the tiled J/K kernels."""
+    return TILE_WIDTHS[l]
 
 
 __all__ = ["LMAX", "NPRIM_MAX", "BASIS_STRIDE", "TILE", "SLOT_NPRIM", "SLOT_ANG", "tile_width"]

@@ -29,6 +29,7 @@ namespace {
 thread_local std::string g_err;
 std::mutex g_mu;
 std::string g_src_dir, g_cache_dir;
+int g_tsw[5] = {8, 4, 4, 2, 1};     // shells per tile edge by angular momentum (jqc_set_tile_widths)
 std::string g_src_tag = "nosrc";   // FNV-1a of every kernel source: stale code objects are never reused
 
 int fail(int code, const char* fmt, ...)
@@ -217,6 +218,33 @@ screen_kernel(const int* __restrict__ tasks, const int ntasks, const unsigned* _
     }
 }
 
+// Primitive-pair prefactors of every shell pair of every tile pair (once per geometry): for tile pair t with widths
+// (wi, wj) the block out[pp_off[t]*27 ...] holds, for shell pair (a, b) and primitive pair (p1, p2),
+//   {c_a c_b exp(-a1 a2 / (a1+a2) |Ra-Rb|^2), 1/(a1+a2), a1+a2}        (reference 1q1t.cu:146-171 caches the same K_ab)
+// at ((a*wj + b)*9 + p1*3 + p2)*3.  Slots of primitives a shell does not have are never read by the J/K kernels.
+__global__ void __launch_bounds__(64)
+pair_table_kernel(const double* __restrict__ basis, const unsigned* __restrict__ tpair_sh,
+                  const unsigned* __restrict__ tpair_wij, const unsigned* __restrict__ pp_off, double* __restrict__ out)
+{
+    const int t = blockIdx.x;
+    const unsigned p = tpair_sh[t], w = tpair_wij[t];
+    const int ish0 = p >> 16, jsh0 = p & 0xffff, wi = w >> 16, wj = w & 0xffff;
+    double* __restrict__ dst = out + (size_t)pp_off[t] * 27;
+    for (int n = threadIdx.x; n < wi * wj * 9; n += 64) {
+        const int pr = n / 9, pp = n - pr * 9, p1 = pp / 3, p2 = pp - p1 * 3;
+        const double* s1 = basis + (size_t)(ish0 + pr / wj) * 12;
+        const double* s2 = basis + (size_t)(jsh0 + pr % wj) * 12;
+        const double dx = s2[0] - s1[0], dy = s2[1] - s1[1], dz = s2[2] - s1[2];
+        const double a1 = s1[5 + 2 * p1], a2 = s2[5 + 2 * p2];
+        const double asum = a1 + a2;
+        const bool have = p1 < (int)s1[10] && p2 < (int)s2[10];
+        const double inv = have ? 1.0 / asum : 0.0;
+        dst[n * 3 + 0] = have ? s1[4 + 2 * p1] * s2[4 + 2 * p2] * exp(-a1 * a2 * inv * (dx * dx + dy * dy + dz * dz)) : 0.0;
+        dst[n * 3 + 1] = inv;
+        dst[n * 3 + 2] = have ? asum : 0.0;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 shell_block_max_kernel(const double* __restrict__ mat, const int n_dm, const int nao, const int* __restrict__ ao_loc,
                        const int nbas, float* __restrict__ out)
@@ -277,6 +305,16 @@ int jqc_set_rys_tables(const double* blob, size_t n)
     return 0;
 }
 
+int jqc_set_tile_widths(const int* widths5)
+{
+    std::lock_guard<std::mutex> lk_(g_mu);
+    for (int l = 0; l < 5; l++) {
+        if (widths5[l] < 1 || widths5[l] > 16) return fail(-1, "tile width of l=%d out of range: %d", l, widths5[l]);
+        g_tsw[l] = widths5[l];
+    }
+    return 0;
+}
+
 int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int rys_lr, int fp32, int algo_variant,
                       int compile_only)
 {
@@ -289,8 +327,8 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
     if (!do_j && !do_k) return fail(-1, "need do_j or do_k");
     char key[128];
-    snprintf(key, sizeof key, "jk%d_%d%d%d%d_j%dk%d_lr%d_%s", algo_variant, li, lj, lk, ll, do_j, do_k, rys_lr,
-             fp32 ? "f32" : "f64");
+    snprintf(key, sizeof key, "jk%d_%d%d%d%d_j%dk%d_lr%d_%s_t%d.%d.%d.%d.%d", algo_variant, li, lj, lk, ll, do_j, do_k,
+             rys_lr, fp32 ? "f32" : "f64", g_tsw[0], g_tsw[1], g_tsw[2], g_tsw[3], g_tsw[4]);
     auto it = g_by_key.find(key);
     if (it != g_by_key.end() && (compile_only || g_kernels[it->second].fn)) return it->second;
     const bool tiled = algo == JQC_ALGO_TILE || algo == JQC_ALGO_TILE1Q || algo == JQC_ALGO_TILE512;
@@ -308,6 +346,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
                                       "-DTILE_1Q=" + std::to_string(algo == JQC_ALGO_TILE1Q ? 1 : 0),
                                       "-DTBLOCK=" + std::to_string(algo == JQC_ALGO_TILE512 ? 512 : 256),
                                       std::string("-DKNAME=") + entry};
+        for (int l = 0; l < 5; l++) d.push_back("-DTSW" + std::to_string(l) + "=" + std::to_string(g_tsw[l]));
         if (v_minw) d.push_back("-DMINW=" + std::to_string(v_minw));
         if (v_rys_l2) d.push_back("-DRYS_LDS_MAX=0");
         if (v_st1) d.push_back("-DST_LDS_MAX=0");
@@ -361,7 +400,7 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
                        double omega, const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* tpair_sh_d,
                        const float* tpair_q_d, const float* q_cond_d, const float* log_dm_d, int nbas, float cut_lo,
                        float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, const int32_t* blk_index_d,
-                       const uint32_t* tpair_ao_d, void* stream)
+                       const uint32_t* tpair_ao_d, const uint32_t* tpair_pp_d, const void* pair_tab_d, void* stream)
 {
     if (handle < 0 || handle >= (int)g_kernels.size() || !g_kernels[handle].fn)
         return fail(-1, "invalid kernel handle %d", handle);
@@ -377,7 +416,7 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
     const void* large = k.fp32 ? (const void*)rys_large32(n) : (const void*)rys_large64(n);
     void* args[] = {&nao, &basis_d, &dm_d, &vj_d, &vk_d, k.fp32 ? (void*)&omega_f : (void*)&omega, &tasks_d, &ntasks,
                     &tpair_sh_d, &tpair_q_d, &q_cond_d, &log_dm_d, &nbas, &cut_lo, &cut_hi, &log_max_dm, &n_dm,
-                    &cheb, &large, &counter_d, &blk_index_d, &tpair_ao_d};
+                    &cheb, &large, &counter_d, &blk_index_d, &tpair_ao_d, &tpair_pp_d, &pair_tab_d};
     const unsigned threads = k.algo == JQC_ALGO_TILE512 ? 512 : 256;
     HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)nblocks, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, args, nullptr));
     return 0;
@@ -392,6 +431,16 @@ int jqc_screen_jk_tasks(const int32_t* tasks_d, int ntasks, int nblocks, const u
     hipLaunchKernelGGL(screen_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, tasks_d, ntasks, pair_sh_d,
                        pair_q_d, log_dm_d, nbas, do_j, do_k, log_cutoff_fp32, log_cutoff_fp64, log_max_dm,
                        (ushort4*)queue_d, (const long long*)region_d, counters_d);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int jqc_pair_table(const double* basis_d, const uint32_t* tpair_sh_d, const uint32_t* tpair_wij_d,
+                   const uint32_t* pp_off_d, int npairs, double* out_d, void* stream)
+{
+    if (npairs <= 0) return 0;
+    hipLaunchKernelGGL(pair_table_kernel, dim3(npairs), dim3(64), 0, (hipStream_t)stream, basis_d, tpair_sh_d,
+                       tpair_wij_d, pp_off_d, out_d);
     HIP_OK(hipGetLastError());
     return 0;
 }

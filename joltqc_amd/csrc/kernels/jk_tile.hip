@@ -30,7 +30,23 @@
 #include "jk_common.h"
 #include "jk_axis.h"
 
-constexpr int ts_of(int l) { return l <= 2 ? 4 : (l == 3 ? 2 : 1); }
+// shells per tile edge, by angular momentum (host side: joltqc_amd/constants.py tile_width; the library passes -DTSWn)
+#ifndef TSW0
+#define TSW0 8
+#endif
+#ifndef TSW1
+#define TSW1 4
+#endif
+#ifndef TSW2
+#define TSW2 4
+#endif
+#ifndef TSW3
+#define TSW3 2
+#endif
+#ifndef TSW4
+#define TSW4 1
+#endif
+constexpr int ts_of(int l) { return l == 0 ? TSW0 : l == 1 ? TSW1 : l == 2 ? TSW2 : l == 3 ? TSW3 : TSW4; }
 constexpr int TSI = ts_of(LI), TSJ = ts_of(LJ), TSK = ts_of(LK), TSL = ts_of(LL);
 constexpr int NQ = TSI * TSJ * TSK * TSL;
 constexpr int T = NFI * NFJ;
@@ -71,7 +87,8 @@ constexpr int NJOB = G * 3 * NROOTS;                                      // pha
 constexpr int NBUF = 2 * G * NROOTS * 3 * NT2 * (int)sizeof(real) <= ST_LDS_MAX ? 2 : 1;
 constexpr int RYS_TAB = (2 * NROOTS + 14) * NROOTS * NCOEF * 2;          // Chebyshev table of this class, in reals
 constexpr bool RYS_IN_LDS = RYS_TAB * (int)sizeof(real) <= RYS_LDS_MAX;
-static_assert(T <= TBLOCK && G >= 1 && NQ <= 256, "tile geometry");
+static_assert(T <= TBLOCK && G >= 1 && NQ <= 65535, "tile geometry");
+static_assert((TSI + TSJ) * BASIS_STRIDE <= TBLOCK && (TSK + TSL) * BASIS_STRIDE <= TBLOCK, "shell rows of a tile pair are staged by one pass");
 static_assert(TBLOCK == 256 || !TILE_1Q, "the lane-per-quartet mode uses 256 threads");
 
 // Rys root `r` only (same tables and branches as rys_roots in jk_common.h)
@@ -149,34 +166,6 @@ __device__ __forceinline__ void flush_tile(double* __restrict__ src, double* __r
 
 __device__ __forceinline__ void lds_add(double* p, double v) { atomicAdd(p, v); }   // ds_add_f64
 
-// survivor `q` of the tile pair: per-wave segments of s_act + the four wave counts
-__device__ __forceinline__ int act_lookup(const unsigned* __restrict__ wc, const unsigned short* __restrict__ act, const int q)
-{
-    const int o1 = wc[0], o2 = o1 + wc[1], o3 = o2 + wc[2];
-    const int w = (q >= o1) + (q >= o2) + (q >= o3);
-    const int base = w == 0 ? 0 : w == 1 ? o1 : w == 2 ? o2 : o3;
-    return act[w * 64 + q - base];
-}
-
-// {c_a c_b K_ab, 1/(a+b), a+b} of primitive pair (p1, p2) of shells (s1, s2): loads, then arithmetic
-struct PairIn { real x1, y1, z1, x2, y2, z2, c1, a1, c2, a2; };
-__device__ __forceinline__ void pair_load(PairIn& p, const real* __restrict__ s1, const real* __restrict__ s2,
-                                          const int p1, const int p2)
-{
-    p.x1 = s1[0]; p.y1 = s1[1]; p.z1 = s1[2];
-    p.x2 = s2[0]; p.y2 = s2[1]; p.z2 = s2[2];
-    p.c1 = s1[4 + 2 * p1]; p.a1 = s1[5 + 2 * p1];
-    p.c2 = s2[4 + 2 * p2]; p.a2 = s2[5 + 2 * p2];
-}
-__device__ __forceinline__ void pair_prefactors(real* __restrict__ dst, const PairIn& p)
-{
-    const real dx = p.x2 - p.x1, dy = p.y2 - p.y1, dz = p.z2 - p.z1;
-    const real asum = p.a1 + p.a2, inv = fast_rcp(asum);
-    dst[0] = p.c1 * p.c2 * exp(-p.a1 * p.a2 * inv * (dx * dx + dy * dy + dz * dz));
-    dst[1] = inv;
-    dst[2] = asum;
-}
-
 // candidate id -> ket shell index c inside the tile.  Lane-per-quartet mode skews c by (a + b + d): the 64 quartets of
 // a wave then spread evenly over the 16 targets of EVERY Fock sub-block (4 lanes per LDS address instead of 16 for
 // J_kl / K_ik / K_jk with the plain order); the row-lane mode keeps the plain order (its register accumulators
@@ -204,10 +193,10 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         const float* __restrict__ log_dm, const int nbas, const float cut_lo, const float cut_hi,
         const float log_max_dm, const int n_dm, const real* __restrict__ rys_cheb, const real* __restrict__ rys_large,
         unsigned long long* __restrict__ counter, const int* __restrict__ blk_index,
-        const unsigned* __restrict__ tpair_ao)
+        const unsigned* __restrict__ tpair_ao, const unsigned* __restrict__ tpair_pp, const real* __restrict__ pair_tab)
 {
-    __shared__ unsigned s_wcnt[2][4];
-    __shared__ unsigned short s_act[256];
+    __shared__ unsigned s_nact[2];              // survivors of the current tile pair (double-buffered by iteration parity)
+    __shared__ unsigned short s_act[NQ];        // their candidate ids, appended wave by wave
     __shared__ real sDij[WJ * WI], sDkl[WL * WK], sDik[WI * WK], sDil[WI * WL], sDjk[WJ * WK], sDjl[WJ * WL];
     __shared__ double sJij[WJ * WI], sJkl[WL * WK], sKik[WI * WK], sKil[WI * WL], sKjk[WJ * WK], sKjl[WJ * WL];
 #if !TILE_1Q
@@ -258,19 +247,16 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     // ---- bra side, once per workgroup: issue every load, then write LDS
     {
         real rb = 0, rrys[NRYS];
-        PairIn pin[(TSI * TSJ * 9 + TBLOCK - 1) / TBLOCK];
         if (tid < (TSI + TSJ) * BASIS_STRIDE) {
             const int sl = tid / BASIS_STRIDE, w = tid - sl * BASIS_STRIDE;
             rb = basis[(sl < TSI ? ish0 + sl : jsh0 + sl - TSI) * BASIS_STRIDE + w];
         }
+        // primitive-pair prefactors of the bra tile pair: a contiguous block of the per-geometry table
+        constexpr int NPB = (TSI * TSJ * 27 + TBLOCK - 1) / TBLOCK;
+        real rpb[NPB];
+        const real* __restrict__ ppb = pair_tab + (size_t)tpair_pp[ij0 + bij] * 27;
 #pragma unroll
-        for (int u = 0; u < (TSI * TSJ * 9 + TBLOCK - 1) / TBLOCK; u++) {
-            const int n = tid + u * TBLOCK;
-            if (n < TSI * TSJ * 9) {
-                const int pr = n / 9, pp = n - pr * 9, p1 = pp / 3, p2 = pp - p1 * 3;
-                pair_load(pin[u], basis + (ish0 + pr / TSJ) * BASIS_STRIDE, basis + (jsh0 + pr % TSJ) * BASIS_STRIDE, p1, p2);
-            }
-        }
+        for (int u = 0; u < NPB; u++) rpb[u] = tid + u * TBLOCK < TSI * TSJ * 27 ? ppb[tid + u * TBLOCK] : real(0);
         if (RYS_IN_LDS) {
 #pragma unroll
             for (int u = 0; u < NRYS; u++) rrys[u] = tid + u * TBLOCK < RYS_TAB ? rys_cheb[tid + u * TBLOCK] : real(0);
@@ -285,12 +271,11 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         for (int n = tid; n < WJ * WK; n += TBLOCK) sKjk[n] = 0;
         for (int n = tid; n < WJ * WL; n += TBLOCK) sKjl[n] = 0;
 #endif
+        if (tid < 2) s_nact[tid] = 0;
         if (tid < (TSI + TSJ) * BASIS_STRIDE) sBas[tid] = rb;
 #pragma unroll
-        for (int u = 0; u < (TSI * TSJ * 9 + TBLOCK - 1) / TBLOCK; u++) {
-            const int n = tid + u * TBLOCK;
-            if (n < TSI * TSJ * 9) pair_prefactors(sPB + n * 3, pin[u]);
-        }
+        for (int u = 0; u < NPB; u++)
+            if (tid + u * TBLOCK < TSI * TSJ * 27) sPB[tid + u * TBLOCK] = rpb[u];
         if (RYS_IN_LDS) {
 #pragma unroll
             for (int u = 0; u < NRYS; u++)
@@ -298,6 +283,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         }
     }
     const real* cheb_tab = RYS_IN_LDS ? sRys : rys_cheb;
+    __syncthreads();            // counters and Fock tiles are clear before any wave appends / accumulates
     STAMP(1);
 
 #if !TILE_1Q
@@ -334,42 +320,17 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             asm volatile("" : "+v"(tid_s));
 #define tid tid_s
             {
-                // ---- issue: screening bounds, ket shell rows, primitive-pair inputs, five density sub-blocks
-                bool cand = false;
-                float sq = 0, sd = -36.8f;
-                if (tid < NQ) {
-                    const int a = tid % TSI, b = (tid / TSI) % TSJ, d = (tid / (TSI * TSJ)) % TSL;
-                    const int c = QC(tid / (TSI * TSJ * TSL), a, b, d);
-                    const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
-                    cand = ish >= jsh && ksh >= lsh && ish * nbas + jsh >= ksh * nbas + lsh;
-                    if (cand) {
-                        sq = q_cond[ish * nbas + jsh] + q_cond[ksh * nbas + lsh];
-#if DO_K
-                        sd = fmaxf(sd, log_dm[ish * nbas + ksh]);
-                        sd = fmaxf(sd, log_dm[jsh * nbas + ksh]);
-                        sd = fmaxf(sd, log_dm[ish * nbas + lsh]);
-                        sd = fmaxf(sd, log_dm[jsh * nbas + lsh]);
-#endif
-#if DO_J
-                        sd = fmaxf(sd, log_dm[ish * nbas + jsh]);
-                        sd = fmaxf(sd, log_dm[ksh * nbas + lsh]);
-#endif
-                    }
-                }
+                // ---- issue: ket shell rows, primitive-pair inputs, five density sub-blocks
                 real rb = 0;
                 if (tid < (TSK + TSL) * BASIS_STRIDE) {
                     const int sl = tid / BASIS_STRIDE, w = tid - sl * BASIS_STRIDE;
                     rb = basis[(sl < TSK ? ksh0 + sl : lsh0 + sl - TSK) * BASIS_STRIDE + w];
                 }
-                PairIn pin[(TSK * TSL * 9 + TBLOCK - 1) / TBLOCK];
+                constexpr int NPK = (TSK * TSL * 27 + TBLOCK - 1) / TBLOCK;
+                real rpk[NPK];
+                const real* __restrict__ ppk = pair_tab + (size_t)tpair_pp[kl0 + kt] * 27;
 #pragma unroll
-                for (int u = 0; u < (TSK * TSL * 9 + TBLOCK - 1) / TBLOCK; u++) {
-                    const int n = tid + u * TBLOCK;
-                    if (n < TSK * TSL * 9) {
-                        const int pr = n / 9, pp = n - pr * 9, p1 = pp / 3, p2 = pp - p1 * 3;
-                        pair_load(pin[u], basis + (ksh0 + pr / TSL) * BASIS_STRIDE, basis + (lsh0 + pr % TSL) * BASIS_STRIDE, p1, p2);
-                    }
-                }
+                for (int u = 0; u < NPK; u++) rpk[u] = tid + u * TBLOCK < TSK * TSL * 27 ? ppk[tid + u * TBLOCK] : real(0);
 #if DO_J
                 TileRegs<WL, WK> rkl;
                 tile_load(rkl, D, nao, l0, k0, tid);
@@ -385,19 +346,47 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 tile_load(rjl, D, nao, j0, l0, tid);
 #endif
                 STAMP(3);
-                // ---- per-quartet screening inside the tile pair (wave64 ballots), survivors compacted per wave
-                const float dq = sq + sd;
-                const bool keep = cand && dq > cut_lo && dq <= cut_hi;
-                const unsigned long long m = __ballot(keep);
-                if (lane == 0 && wave < 4) s_wcnt[parity][wave] = __popcll(m);
-                if (keep) s_act[wave * 64 + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+                // ---- per-quartet screening of the NQ candidates of the tile pair (wave64 ballots); every wave appends
+                //      its survivors to the queue through one LDS counter
+                if (tid == 0) s_nact[parity ^ 1] = 0;          // next iteration's counter (last read before this point)
+#pragma unroll 2
+                for (int cand0 = 0; cand0 < NQ; cand0 += TBLOCK) {
+                    const int cd = cand0 + tid;
+                    bool keep = false;
+                    if (cd < NQ) {
+                        const int a = cd % TSI, b = (cd / TSI) % TSJ, d = (cd / (TSI * TSJ)) % TSL;
+                        const int c = QC(cd / (TSI * TSJ * TSL), a, b, d);
+                        const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
+                        if (ish >= jsh && ksh >= lsh && ish * nbas + jsh >= ksh * nbas + lsh) {
+                            const float sq = q_cond[ish * nbas + jsh] + q_cond[ksh * nbas + lsh];
+                            float sd = -36.8f;
+#if DO_K
+                            sd = fmaxf(sd, log_dm[ish * nbas + ksh]);
+                            sd = fmaxf(sd, log_dm[jsh * nbas + ksh]);
+                            sd = fmaxf(sd, log_dm[ish * nbas + lsh]);
+                            sd = fmaxf(sd, log_dm[jsh * nbas + lsh]);
+#endif
+#if DO_J
+                            sd = fmaxf(sd, log_dm[ish * nbas + jsh]);
+                            sd = fmaxf(sd, log_dm[ksh * nbas + lsh]);
+#endif
+                            const float dq = sq + sd;
+                            keep = dq > cut_lo && dq <= cut_hi;
+                        }
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (m) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&s_nact[parity], (unsigned)__popcll(m));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (keep) s_act[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)cd;
+                    }
+                }
                 // ---- write LDS
                 if (tid < (TSK + TSL) * BASIS_STRIDE) sBas[OFF_K + tid] = rb;
 #pragma unroll
-                for (int u = 0; u < (TSK * TSL * 9 + TBLOCK - 1) / TBLOCK; u++) {
-                    const int n = tid + u * TBLOCK;
-                    if (n < TSK * TSL * 9) pair_prefactors(sPK + n * 3, pin[u]);
-                }
+                for (int u = 0; u < NPK; u++)
+                    if (tid + u * TBLOCK < TSK * TSL * 27) sPK[tid + u * TBLOCK] = rpk[u];
 #if DO_J
                 tile_store(sDkl, rkl, tid);
 #endif
@@ -412,8 +401,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             STAMP(4);
             __syncthreads();
             STAMP(5);
-            const unsigned* wc = s_wcnt[parity];
-            const int nact = wc[0] + wc[1] + wc[2] + wc[3];
+            const int nact = __builtin_amdgcn_readfirstlane((int)s_nact[parity]);
             if (nact == 0) continue;
             const int npi = __builtin_amdgcn_readfirstlane((int)sBas[10]), npj = __builtin_amdgcn_readfirstlane((int)sBas[OFF_J + 10]);
             const int npk = __builtin_amdgcn_readfirstlane((int)sBas[OFF_K + 10]), npl = __builtin_amdgcn_readfirstlane((int)sBas[OFF_L + 10]);
@@ -421,8 +409,8 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 
 #if TILE_1Q
             // ---------------- one quartet per lane: everything in registers, then LDS Fock tiles
-            if (tid < nact) {
-                const int qd = act_lookup(wc, s_act, tid);
+            for (int q1 = tid; q1 < nact; q1 += TBLOCK) {
+                const int qd = s_act[q1];
                 const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
                 const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
                 const real* bi = sBas + a * BASIS_STRIDE;
@@ -580,7 +568,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     const int r = rem / 3, ax = rem - r * 3;
                     const int qa = sa * per + step;
                     if (qa >= nact) continue;
-                    const int qd = act_lookup(wc, s_act, qa);
+                    const int qd = s_act[qa];
                     const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
                     const real* bi = sBas + a * BASIS_STRIDE;
                     const real* bj = sBas + OFF_J + b * BASIS_STRIDE;
@@ -670,7 +658,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     const bool on = lane_on && qi < nact;
                     int a = 0, b = 0, c = 0, d = 0;
                     if (on) {
-                        const int qd = act_lookup(wc, s_act, qi);
+                        const int qd = s_act[qi];
                         a = qd % TSI; b = (qd / TSI) % TSJ; d = (qd / (TSI * TSJ)) % TSL; c = QC(qd / (TSI * TSJ * TSL), a, b, d);
                     }
                     const real* bi = sBas + a * BASIS_STRIDE;

@@ -239,7 +239,7 @@ class _TileTables:
         goff, gkey = layout.group_offset, layout.group_key
         self.offset: Dict[Tuple[int, int], int] = {}
         self.q_host: Dict[Tuple[int, int], np.ndarray] = {}
-        sh_all, q_all, off = [], [], 0
+        sh_all, q_all, w_all, off = [], [], [], 0
         for gi in range(layout.ngroups):
             wi = tile_width(int(gkey[gi, 0]))
             assert (goff[gi + 1] - goff[gi]) % wi == 0, "layout groups must be padded to the tile width"
@@ -262,20 +262,39 @@ class _TileTables:
                 self.q_host[gi, gj] = qq[order].astype(np.float32)
                 sh_all.append(sh)
                 q_all.append(self.q_host[gi, gj])
+                w_all.append(np.full(sh.size, (wi << 16) | wj, dtype=np.uint32))
                 off += sh.size
         self.sh_host = np.concatenate(sh_all) if off else np.zeros(1, dtype=np.uint32)
+        self.wij_host = np.concatenate(w_all) if off else np.zeros(1, dtype=np.uint32)
         assert layout.nao < 65536, "tile-pair AO offsets are packed into 16 bits"
         aol = np.asarray(layout.ao_loc).astype(np.uint32)
         self.ao_host = ((aol[self.sh_host >> np.uint32(16)] << np.uint32(16)) | aol[self.sh_host & np.uint32(0xffff)]).astype(np.uint32)
         if host_only:
             return
-        self.ao = torch.from_numpy(self.ao_host.view(np.int32)).to(dev)
         if off:
             self.sh = torch.from_numpy(self.sh_host.view(np.int32)).to(dev)
             self.q = torch.from_numpy(np.concatenate(q_all)).to(dev)
         else:
             self.sh = torch.zeros(1, dtype=torch.int32, device=dev)
             self.q = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ao = torch.from_numpy(self.ao_host.view(np.int32)).to(dev)
+        # primitive-pair prefactor table of every tile pair (jqc_pair_table), fp64 and (lazily) fp32
+        nshp = (self.wij_host >> np.uint32(16)).astype(np.int64) * (self.wij_host & np.uint32(0xffff)).astype(np.int64)
+        pp_off = np.concatenate([[0], np.cumsum(nshp)])
+        assert pp_off[-1] < 2 ** 32
+        self.pp_off = torch.from_numpy(pp_off[:-1].astype(np.uint32).view(np.int32)).to(dev)
+        self.pair_tab = torch.empty(max(int(pp_off[-1]), 1) * 27, dtype=torch.float64, device=dev)
+        self._pair_tab32 = None
+        if off:
+            wij_d = torch.from_numpy(self.wij_host.view(np.int32)).to(dev)
+            _lib.check(_lib.lib().jqc_pair_table(layout.basis_data_fp64["packed"].data_ptr(), self.sh.data_ptr(),
+                                                 wij_d.data_ptr(), self.pp_off.data_ptr(), int(off),
+                                                 self.pair_tab.data_ptr(), _lib.stream_ptr()))
+
+    def pair_tab32(self):
+        if self._pair_tab32 is None:
+            self._pair_tab32 = self.pair_tab.float()
+        return self._pair_tab32
 
 
 def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float, want, shard=None):
@@ -468,7 +487,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                                                     tabs_d.data_ptr() + row * 32, tab.shape[0], nblk, tt.sh.data_ptr(),
                                                     tt.q.data_ptr(), tt.q_dev.data_ptr(), log_dm_cond.data_ptr(), nbas,
                                                     log_cutoff_fp64 if mixed else log_cutoff_fp32, INF, log_max_dm, n_dm,
-                                                    tile_counts[0].data_ptr(), idx_p, tt.ao.data_ptr(), sp))
+                                                    tile_counts[0].data_ptr(), idx_p, tt.ao.data_ptr(), tt.pp_off.data_ptr(),
+                                                    tt.pair_tab.data_ptr(), sp))
                     if probing:
                         ev1.record(sid)
                         state["stats"].setdefault("probe_events", []).append((ev0, ev1))
@@ -481,7 +501,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                                                         tabs_d.data_ptr() + row * 32, tab.shape[0], nblk,
                                                         tt.sh.data_ptr(), tt.q.data_ptr(), tt.q_dev.data_ptr(),
                                                         log_dm_cond.data_ptr(), nbas, log_cutoff_fp32, log_cutoff_fp64,
-                                                        log_max_dm, n_dm, tile_counts[1].data_ptr(), idx_p, tt.ao.data_ptr(), sp))
+                                                        log_max_dm, n_dm, tile_counts[1].data_ptr(), idx_p, tt.ao.data_ptr(), tt.pp_off.data_ptr(),
+                                                        tt.pair_tab32().data_ptr(), sp))
                         n_launch += 1
                     row += tab.shape[0]
                 for st_ in side:
