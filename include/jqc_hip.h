@@ -32,6 +32,7 @@ extern "C" {
 #define JQC_VARIANT_MINW(n) ((n) << 4) /* waves per SIMD the register allocation leaves room for (0 = kernel default) */
 #define JQC_VARIANT_RYS_L2 (1 << 8)    /* read the Rys table through L2 instead of staging it in LDS */
 #define JQC_VARIANT_ST1 (1 << 9)       /* single-buffered TRR array (less LDS, one more barrier per primitive combination) */
+#define JQC_VARIANT_WSYNC (1 << 10)    /* row-lane mode with every quartet inside one wave: no workgroup barrier per step */
 
 const char* jqc_last_error(void);
 const char* jqc_version(void);
@@ -65,8 +66,9 @@ int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, do
 /* Launch of a tiled J/K kernel (JQC_ALGO_TILE / JQC_ALGO_TILE1Q).  No quartet queue: one workgroup per (bra tile
  * pair, chunk of consecutive ket tile pairs); screening (same predicate as jqc_screen_jk_tasks) happens inside the
  * workgroup.
- *   tasks_d     int32[ntasks][8] = {ij0, nij, kl0, nkl, nchunk, blk0, cnt, kchunk}: rectangle of the two tile-pair
- *               lists; the row owns nij*nchunk workgroups starting at blk0, nchunk = ceil(nkl / kchunk)
+ *   tasks_d     int32[ntasks][8] = {ij0, nij, kl0, nkl, nchunk, blk0, cnt, kchunk | nsplit<<16}: rectangle of the two
+ *               tile-pair lists; the row owns nij*nchunk*nsplit workgroups starting at blk0, nchunk = ceil(nkl / kchunk);
+ *               nsplit >= 1 workgroups share one (bra pair, ket chunk), each taking a contiguous range of candidates
  *   nblocks     total workgroups of the launch
  *   tpair_sh_d  uint32[...] = first shell of tile i <<16 | first shell of tile j; tpair_q_d = max log-Schwarz of the
  *               pair, each list sorted descending (a workgroup stops at the first ket pair below the cutoff)

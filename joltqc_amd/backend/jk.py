@@ -49,6 +49,9 @@ def select_algo(ang, fp32=False):
             v = int(f[1:])
             if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > TILE1Q_FORCE_MAX:
                 return _lib.ALGO_TILE
+            nf = lambda l: (l + 1) * (l + 2) // 2
+            if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or nf(ang[0]) * nf(ang[1]) > 64):
+                v &= ~0x400                          # a quartet must fit one wave for the wave-local variant
             return v
         if f in ("0", "1q1t"):
             return _lib.ALGO_1Q1T

@@ -53,7 +53,14 @@ constexpr int T = NFI * NFJ;
 #ifndef TBLOCK
 #define TBLOCK 256   // threads per workgroup (512: two waves per SIMD share one set of LDS tiles; row-lane mode only)
 #endif
-constexpr int G = TBLOCK / T;
+#ifndef WSYNC
+#define WSYNC 0     // row-lane mode, T <= 64: every quartet lives inside ONE wave (phase A by lanes of the same wave), so the
+                    // step loop needs no workgroup barrier and the waves of a workgroup drift apart (LDS atomics of one
+                    // overlap the arithmetic of another); costs the 64 % T lanes left over in every wave
+#endif
+constexpr int NWAVE = TBLOCK / 64;
+constexpr int GW = T <= 64 ? 64 / T : 0;          // quartets per wave (WSYNC)
+constexpr int G = WSYNC ? NWAVE * GW : TBLOCK / T;
 #ifndef ECAP
 #define ECAP 64
 #endif
@@ -84,7 +91,15 @@ constexpr int E = CW * NFL;
 constexpr int WI = TSI * NFI, WJ = TSJ * NFJ, WK = TSK * NFK, WL = TSL * NFL;
 constexpr int NT2 = (LIJ + 1) * (LKL + 1);
 constexpr int NJOB = G * 3 * NROOTS;                                      // phase-A jobs per step
-constexpr int NBUF = 2 * G * NROOTS * 3 * NT2 * (int)sizeof(real) <= ST_LDS_MAX ? 2 : 1;
+constexpr int NBUF = (!WSYNC && 2 * G * NROOTS * 3 * NT2 * (int)sizeof(real) <= ST_LDS_MAX) ? 2 : 1;
+static_assert(!WSYNC || (T <= 64 && !TILE_1Q), "WSYNC needs a quartet to fit one wave");
+#if WSYNC
+// ordering of LDS traffic inside one wave is kept by the hardware (one in-order DS queue per wave); the compiler only
+// has to keep the program order of the accesses
+#define STEP_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define STEP_SYNC() __syncthreads()
+#endif
 constexpr int RYS_TAB = (2 * NROOTS + 14) * NROOTS * NCOEF * 2;          // Chebyshev table of this class, in reals
 constexpr bool RYS_IN_LDS = RYS_TAB * (int)sizeof(real) <= RYS_LDS_MAX;
 static_assert(T <= TBLOCK && G >= 1 && NQ <= 65535, "tile geometry");
@@ -159,7 +174,9 @@ __device__ __forceinline__ void flush_tile(double* __restrict__ src, double* __r
         const double v = src[idx];
         if (v != 0.0) {
             src[idx] = 0.0;
+#ifndef NO_FLUSH   // timing-only ablation (wrong results): no global atomics
             if (r0 + r < nao && c0 + c < nao) atomic_add_f64(out + (size_t)(r0 + r) * nao + c0 + c, v);
+#endif
         }
     }
 }
@@ -233,8 +250,12 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     }
     STAMP(0);
     const int* __restrict__ tk = tasks + row * 8;
-    const int ij0 = tk[0], kl0 = tk[2], nkl = tk[3], nchunk = tk[4], kchunk = tk[7];
-    const int lb = blockIdx.x - tk[5];
+    const int ij0 = tk[0], kl0 = tk[2], nkl = tk[3], nchunk = tk[4], kchunk = tk[7] & 0xffff;
+    // small launches: the candidates of one (bra pair, ket chunk) are dealt to nsplit workgroups (contiguous id ranges)
+    const int nsplit = tk[7] >> 16;
+    const int lb0 = blockIdx.x - tk[5];
+    const int lb = lb0 / nsplit, sid = lb0 - lb * nsplit;
+    const int cand_lo = NQ * sid / nsplit, cand_hi = NQ * (sid + 1) / nsplit;
     const int bij = lb / nchunk, ch = lb - bij * nchunk;
     const int kt0 = ch * kchunk, kt1 = min(nkl, kt0 + kchunk);
     const unsigned pij = tpair_sh[ij0 + bij], aoij = tpair_ao[ij0 + bij];
@@ -287,8 +308,13 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     STAMP(1);
 
 #if !TILE_1Q
+#if WSYNC
+    const int qslot = lane / T, slot = wave * GW + qslot, t = lane - qslot * T;
+    const bool lane_on = qslot < GW;
+#else
     const int slot = tid / T, t = tid - slot * T;
     const bool lane_on = slot < G;
+#endif
     const int ci = t / NFJ, cj = t - ci * NFJ;
     const int ibra[3] = {TI.x[ci], TI.y[ci], TI.z[ci]};
     const int jbra[3] = {TJ.x[cj], TJ.y[cj], TJ.z[cj]};
@@ -350,10 +376,10 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 //      its survivors to the queue through one LDS counter
                 if (tid == 0) s_nact[parity ^ 1] = 0;          // next iteration's counter (last read before this point)
 #pragma unroll 2
-                for (int cand0 = 0; cand0 < NQ; cand0 += TBLOCK) {
+                for (int cand0 = cand_lo; cand0 < cand_hi; cand0 += TBLOCK) {
                     const int cd = cand0 + tid;
                     bool keep = false;
-                    if (cd < NQ) {
+                    if (cd < cand_hi) {
                         const int a = cd % TSI, b = (cd / TSI) % TSJ, d = (cd / (TSI * TSJ)) % TSL;
                         const int c = QC(cd / (TSI * TSJ * TSL), a, b, d);
                         const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
@@ -563,8 +589,14 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 const int lp = cmb % npl;
                 const int kp = cmb / npl;
                 real* __restrict__ buf = sT + (NBUF > 1 ? (m & 1) : 0) * (G * NROOTS * 3 * NT2);
+#if WSYNC
+                for (int job = lane; job < GW * 3 * NROOTS; job += 64) {
+                    const int sl = job / (3 * NROOTS), rem = job - sl * (3 * NROOTS);
+                    const int sa = wave * GW + sl;
+#else
                 for (int job = tid; job < NJOB; job += TBLOCK) {
                     const int sa = job / (3 * NROOTS), rem = job - sa * (3 * NROOTS);
+#endif
                     const int r = rem / 3, ax = rem - r * 3;
                     const int qa = sa * per + step;
                     if (qa >= nact) continue;
@@ -651,7 +683,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 int item = 0;
                 if (NBUF > 1) {
                     phase_a(0);
-                    __syncthreads();
+                    STEP_SYNC();
                 }
                 for (int step = 0; step < per; step++) {
                     const int qi = slot * per + step;
@@ -695,7 +727,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             if (item + 1 < nitem) phase_a(item + 1);
                         } else {
                             phase_a(item);
-                            __syncthreads();
+                            STEP_SYNC();
                         }
                         STAMP(10);
                         // ---------------- phase B: row lanes: own bra slice, ket HRR, integral accumulation
@@ -740,7 +772,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             }
                         }
                         STAMP(11);
-                        __syncthreads();
+                        STEP_SYNC();
                         STAMP(12);
                     }
 

@@ -298,8 +298,9 @@ class _TileTables:
 
 
 def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float, want, shard=None):
-    """Task tables of the tiled kernels for one call: {ang: int32[ntasks, 8]} with rows
-    (ij0, nij, kl0, nkl, 0, blk0, 0, 0); one workgroup per (tile pair ij, tile pair kl)."""
+    """Task tables of the tiled kernels for one call: {ang: (int32[ntasks, 8], nblocks, nprim patterns, coarse index)}
+    with rows (ij0, nij, kl0, nkl, nchunk, blk0, counter slot, kchunk | nsplit << 16) (include/jqc_hip.h)."""
+    from ..constants import tile_width
     gkey = layout.group_key
     ng = layout.ngroups
     pair_cut = math.log(PAIR_CUTOFF) - log_max_dm
@@ -343,12 +344,20 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
         # the class still fills the chip (>= TARGET_WGS workgroups) the chunks grow up to KCHUNK_MAX
         nblk1 = sum(r[1] * r[3] for r in rows)
         kchunk = int(min(KCHUNK_MAX, max(1, nblk1 // TARGET_WGS)))
+        # small launches (few tile pairs, e.g. the f classes of a small molecule): deal the candidates of every tile
+        # pair to nsplit workgroups so that the class still spreads over the chip
+        nq = 1
+        for l in ang:
+            nq *= tile_width(l)
+        nsplit = 1
+        if kchunk == 1 and nblk1 < SPLIT_BELOW_WGS:
+            nsplit = int(max(1, min(NSPLIT_MAX, SPLIT_BELOW_WGS // max(nblk1, 1), nq // 16)))
         tab = np.zeros((len(rows), 8), dtype=np.int32)
         blk = 0
         for n, (ij0, nij, kl0, nkl, _) in enumerate(rows):
             nchunk = -(-nkl // kchunk)
-            tab[n] = (ij0, nij, kl0, nkl, nchunk, blk, 0, kchunk)
-            blk += nij * nchunk
+            tab[n] = (ij0, nij, kl0, nkl, nchunk, blk, 0, kchunk | (nsplit << 16))
+            blk += nij * nchunk * nsplit
             assert blk < 2 ** 31
         # coarse index: task row of every 256th workgroup (the kernel probes forward from there)
         starts = tab[:, 5].astype(np.int64)
@@ -358,6 +367,8 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
 
 
 KCHUNK_MAX = int(__import__('os').environ.get('JQC_KCHUNK_MAX', '16'))
+SPLIT_BELOW_WGS = int(__import__('os').environ.get('JQC_SPLIT_BELOW', '1024'))
+NSPLIT_MAX = int(__import__('os').environ.get('JQC_NSPLIT_MAX', '8'))
 TARGET_WGS = int(__import__('os').environ.get('JQC_TARGET_WGS', '4096'))
 
 

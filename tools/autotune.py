@@ -15,10 +15,14 @@ AVAIL = os.path.join(CACHE, "available.json")
 os.environ["JQC_KERNEL_CACHE"] = CACHE
 
 MINW = lambda n: n << 4
-RYS_L2, ST1 = 1 << 8, 1 << 9
+RYS_L2, ST1, WSYNC = 1 << 8, 1 << 9, 1 << 10
 CANDIDATES = [2 | MINW(1), 2 | MINW(2), 2 | MINW(3),
               1 | MINW(1), 1 | MINW(2), 1 | MINW(1) | RYS_L2, 1 | MINW(2) | RYS_L2, 1 | MINW(2) | RYS_L2 | ST1,
-              1 | MINW(3) | RYS_L2 | ST1, 3, 3 | RYS_L2]
+              1 | MINW(3) | RYS_L2 | ST1,
+              1 | MINW(1) | WSYNC, 1 | MINW(2) | WSYNC, 1 | MINW(1) | RYS_L2 | WSYNC, 1 | MINW(2) | RYS_L2 | WSYNC,
+              1 | MINW(3) | RYS_L2 | WSYNC]
+if os.environ.get("JQC_TUNE_ONLY"):
+    CANDIDATES = [int(x, 0) for x in os.environ["JQC_TUNE_ONLY"].split(",")]
 MAX_1Q = 200
 
 
