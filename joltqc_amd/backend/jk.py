@@ -22,6 +22,11 @@ def _table():
     return {}
 
 
+def class_cost_table():
+    """{class key: measured ns per dispatched quartet} (gfx950_scheme.json, tools/class_profile.py)."""
+    return _table().get("ns_per_quartet", {})
+
+
 TILE1Q_MAX_NINT = int(os.environ.get("JQC_TILE1Q_MAX", "108"))   # above this the lane-per-quartet body spills heavily
 TILE1Q_FORCE_MAX = 200    # largest integral block the lane-per-quartet mode is ever tried on (512 VGPRs at 1 wave/SIMD)
 
@@ -38,6 +43,17 @@ def class_key(ang):
     return str(1000 * li + 100 * lj + 10 * lk + ll)
 
 
+def forced_variant(ang, v):
+    """Variant code ``v`` adjusted to what class ``ang`` supports: lane-per-quartet only where the integral block fits,
+    the wave-local variant only where a quartet fits one wave."""
+    if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > TILE1Q_FORCE_MAX:
+        return _lib.ALGO_TILE
+    nf = lambda l: (l + 1) * (l + 2) // 2
+    if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or nf(ang[0]) * nf(ang[1]) > 64):
+        v &= ~0x400
+    return v
+
+
 def select_algo(ang, fp32=False):
     """Algorithm + tuning variant of class ``ang`` (low 4 bits: lib.ALGO_*, bits 4-7: waves per SIMD, bit 8: Rys table
     through L2, bit 9: single TRR buffer; include/jqc_hip.h JQC_VARIANT_*)."""
@@ -45,14 +61,8 @@ def select_algo(ang, fp32=False):
     forced = os.environ.get("JQC_JK_ALGO")
     if forced:
         f = forced.lower()
-        if f.startswith("v"):                         # raw variant code, e.g. v289; lane-per-quartet only where it fits
-            v = int(f[1:])
-            if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > TILE1Q_FORCE_MAX:
-                return _lib.ALGO_TILE
-            nf = lambda l: (l + 1) * (l + 2) // 2
-            if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or nf(ang[0]) * nf(ang[1]) > 64):
-                v &= ~0x400                          # a quartet must fit one wave for the wave-local variant
-            return v
+        if f.startswith("v"):                         # raw variant code, e.g. v289
+            return forced_variant(ang, int(f[1:]))
         if f in ("0", "1q1t"):
             return _lib.ALGO_1Q1T
         if f in ("2", "tile1q"):

@@ -331,11 +331,10 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
                         n_kl = min(nkl_all, int(np.searchsorted(-qkl, -thr, side="left")))
                         if n_kl <= 0:
                             break
-                        strip_no += 1
-                        if strip_no % world != rank:
-                            continue                      # another rank's share of the quartet work
                         rows.append((tt.offset[gi, gj] + s0, n_ij, tt.offset[gk, gl], n_kl,
                                      (int(gkey[gi, 1]), int(gkey[gj, 1]), int(gkey[gk, 1]), int(gkey[gl, 1]))))
+    if world > 1:
+        per_class = _shard_rows(per_class, rank, world)
     plans = {}
     for ang, rows in per_class.items():
         if not rows:
@@ -364,6 +363,37 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
         index = (np.searchsorted(starts, np.arange(0, blk + 256, 256), side="right") - 1).astype(np.int32)
         plans[ang] = (tab, blk, [r[4] for r in rows], index)
     return plans
+
+
+def _shard_rows(per_class, rank, world):
+    """This rank's share of the task rows.  Every rank evaluates the same deterministic assignment: classes are taken
+    in order of decreasing cost (tile-pair products x model FLOP per quartet); a class worth more than half a rank's
+    fair share is dealt row by row (strips of the Schwarz-sorted bra list) round-robin over the ranks, a cheaper class
+    goes as a whole to the least loaded rank -- so a small molecule does not pay every class's launch on every rank."""
+    from ..roofline import quartet_flops
+    measured = _router.class_cost_table()          # ns per quartet of the class on gfx950, where measured
+    unit = {a: measured.get(_router.class_key(a), 1.5e-4 * float(quartet_flops(a))) for a in per_class}
+    cost = {a: sum(r[1] * r[3] for r in rows) * unit[a] for a, rows in per_class.items()}
+    fair = sum(cost.values()) / world
+    load = [0.0] * world
+    mine = {}
+    start = 0
+    for a in sorted(per_class, key=lambda a: (-cost[a], a)):
+        rows = per_class[a]
+        if cost[a] > 0.5 * fair and len(rows) >= world:
+            w = [r[1] * r[3] for r in rows]
+            for n, r in enumerate(rows):
+                tgt = (n + start) % world
+                load[tgt] += w[n] * unit[a]
+                if tgt == rank:
+                    mine.setdefault(a, []).append(r)
+            start += len(rows) % world
+        else:
+            tgt = min(range(world), key=lambda k: (load[k], k))
+            load[tgt] += cost[a]
+            if tgt == rank:
+                mine[a] = list(rows)
+    return mine
 
 
 KCHUNK_MAX = int(__import__('os').environ.get('JQC_KCHUNK_MAX', '16'))

@@ -147,3 +147,70 @@ def test_benzene_svp_parity_full_size():
     scale = max(np.abs(rj).max(), np.abs(rk).max())
     assert np.abs(_np(vj) - rj).max() < 1e-11 * scale
     assert np.abs(_np(vk) - rk).max() < 1e-11 * scale
+
+
+def test_ket_chunks_and_workgroup_splits(monkeypatch):
+    """Launch geometry must not change the result: long ket chunks per workgroup (bra-resident loop, J_ij kept in LDS
+    across ket pairs) and candidates of one tile pair dealt to several workgroups."""
+    from joltqc_amd.pyscf import jk as jkmod
+    from oracle import dense
+    mol, lay, _ = _setup(H2O, "def2-tzvpp")
+    dm = _dm(mol.nao)
+    rj, rk = dense.get_jk(lay, dm, hermi=1)
+    scale = max(np.abs(rj).max(), np.abs(rk).max())
+    for target, kmax, split_below, nsplit in ((1, 7, 0, 1), (1 << 30, 1, 1 << 30, 8), (4, 3, 1 << 30, 4)):
+        monkeypatch.setattr(jkmod, "TARGET_WGS", target)
+        monkeypatch.setattr(jkmod, "KCHUNK_MAX", kmax)
+        monkeypatch.setattr(jkmod, "SPLIT_BELOW_WGS", split_below)
+        monkeypatch.setattr(jkmod, "NSPLIT_MAX", nsplit)
+        get_jk = jkmod.generate_jk_kernel(lay, cutoff_fp64=1e-13, cutoff_fp32=1e-13)
+        vj, vk = get_jk(mol, dm, hermi=1)
+        assert np.abs(_np(vj) - rj).max() < 1e-11 * scale, (target, kmax, nsplit)
+        assert np.abs(_np(vk) - rk).max() < 1e-11 * scale, (target, kmax, nsplit)
+        n64, _, _ = get_jk.quartet_counts()
+        assert n64 == len(dense.canonical_quartets(lay))
+
+
+@pytest.mark.parametrize("variant", [0x11, 0x21 | 0x100, 0x11 | 0x400, 0x21 | 0x100 | 0x200, 0x12, 0x32])
+def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
+    """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
+    L2 | single TRR buffer | wave-local steps; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.
+    Role of the reference's 1q1t == 1qnt cross-check (jqc/backend/data/generate_fragment.py:278-309)."""
+    from joltqc_amd.backend import jk as router
+    from oracle import dense
+    monkeypatch.setenv("JQC_JK_ALGO", "v%d" % variant)
+    router.gen_jk_kernel.cache_clear()
+    basis = {"O": [[0, [11.0, 0.3], [2.1, 0.5], [0.5, 0.4]], [0, [0.3, 1.0]], [1, [3.4, 0.4], [0.7, 0.7]], [1, [0.2, 1.0]],
+                   [2, [1.2, 1.0]], [3, [1.4, 1.0]]],
+             "H": [[0, [5.0, 0.3], [0.8, 0.8]], [0, [0.2, 1.0]], [1, [0.8, 1.0]], [2, [1.0, 1.0]]]}
+    mol, lay, get_jk = _setup(H2O, basis)
+    dm = _dm(mol.nao)
+    vj, vk = get_jk(mol, dm, hermi=1)
+    rj, rk = dense.get_jk(lay, dm, hermi=1)
+    scale = max(np.abs(rj).max(), np.abs(rk).max())
+    router.gen_jk_kernel.cache_clear()
+    assert np.abs(_np(vj) - rj).max() < 1e-11 * scale
+    assert np.abs(_np(vk) - rk).max() < 1e-11 * scale
+
+
+def test_pair_prefactor_table_matches_closed_form():
+    """jqc_pair_table: {c_a c_b exp(-a b/(a+b) R^2), 1/(a+b), a+b} per primitive pair (reference 1q1t.cu:146-171)."""
+    from joltqc_amd.pyscf import jk as jkmod
+    mol, lay, _ = _setup(H2O, "def2-svp")
+    tt = jkmod._TileTables(lay, 0.0)
+    tab = _np(tt.pair_tab).reshape(-1, 9, 3)
+    off = _np(tt.pp_off).view(np.uint32)
+    P = lay.packed
+    for t in (0, len(tt.sh_host) // 2, len(tt.sh_host) - 1):
+        ish0, jsh0 = int(tt.sh_host[t]) >> 16, int(tt.sh_host[t]) & 0xffff
+        wi, wj = int(tt.wij_host[t]) >> 16, int(tt.wij_host[t]) & 0xffff
+        for a in range(wi):
+            for b in range(wj):
+                s1, s2 = P[ish0 + a], P[jsh0 + b]
+                r2 = float(((s1[:3] - s2[:3]) ** 2).sum())
+                for p1 in range(int(s1[10])):
+                    for p2 in range(int(s2[10])):
+                        a1, a2 = s1[5 + 2 * p1], s2[5 + 2 * p2]
+                        ref = (s1[4 + 2 * p1] * s2[4 + 2 * p2] * np.exp(-a1 * a2 / (a1 + a2) * r2), 1 / (a1 + a2), a1 + a2)
+                        got = tab[int(off[t]) + a * wj + b, p1 * 3 + p2]
+                        assert np.allclose(got, ref, rtol=1e-13, atol=0)
