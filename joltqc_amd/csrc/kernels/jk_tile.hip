@@ -669,7 +669,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 
 #pragma unroll
             for (int CH = 0; CH < NCH; CH++) {
-                // register accumulators carried across consecutive quartets of this lane
+                // register accumulators carried across consecutive quartets of this lane that share the destination block
                 double jkl_acc[E], kjk_acc[CW], kjl_acc[NFL];
 #pragma unroll
                 for (int e = 0; e < E; e++) jkl_acc[e] = 0;
@@ -677,8 +677,6 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 for (int n = 0; n < CW; n++) kjk_acc[n] = 0;
 #pragma unroll
                 for (int n = 0; n < NFL; n++) kjl_acc[n] = 0;
-                int key_kl = -1, key_jk = -1, key_jl = -1;      // local ids of the block the accumulators belong to
-                int pjA = 0;                                     // jA of the accumulators (bra side of K_jk/K_jl)
 
                 int item = 0;
                 if (NBUF > 1) {
@@ -776,96 +774,85 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         STAMP(12);
                     }
 
-                    // ---------------- contraction with the density sub-blocks, accumulation in the LDS Fock tiles
+                    // ---------------- contraction with the density sub-blocks.  All LDS reads and arithmetic first, every
+                    // LDS atomic of the step at the end: the DS queue of a CU is in order, so a read issued behind a
+                    // same-address f64 atomic waits for its serialised lanes (~9 cycles each, tools/micro/lds_atomic_bench.hip);
+                    // issued last, the atomics drain under the next step's arithmetic.
                     const int iA = a * NFI + ci, jA = b * NFJ + cj;
                     const int kb = c * NFK + CH * CW, lbs = d * NFL;
-                    const int nk_kl = on ? c * TSL + d : -1, nk_jk = on ? b * TSK + c : -1, nk_jl = on ? b * TSL + d : -1;
-#if DO_J
-                    if (key_kl >= 0 && key_kl != nk_kl) {
-                        const int pk = (key_kl / TSL) * NFK + CH * CW, pl = (key_kl % TSL) * NFL;
-#pragma unroll
-                        for (int kk = 0; kk < CW; kk++)
-#pragma unroll
-                            for (int cl = 0; cl < NFL; cl++) {
-                                lds_add(&sJkl[(pl + cl) * WK + pk + kk], jkl_acc[kk * NFL + cl]);
-                                jkl_acc[kk * NFL + cl] = 0;
-                            }
+                    // does the next quartet of this lane still belong to the same (k,l) / (j,k) / (j,l) block?
+                    bool keep_kl = false, keep_jk = false, keep_jl = false;
+                    if (on && step + 1 < per && qi + 1 < nact) {
+                        const int q2 = s_act[qi + 1];
+                        const int a2 = q2 % TSI, b2 = (q2 / TSI) % TSJ, d2 = (q2 / (TSI * TSJ)) % TSL;
+                        const int c2 = QC(q2 / (TSI * TSJ * TSL), a2, b2, d2);
+                        keep_kl = c2 == c && d2 == d;
+                        keep_jk = b2 == b && c2 == c;
+                        keep_jl = b2 == b && d2 == d;
                     }
-                    key_kl = nk_kl;
+                    real s_ij = 0, s_ik[CW], kil[NFL];
                     if (on) {
-                        const real dij = sDij[jA * WI + iA];
-                        real s = 0;
+#if DO_J
+                        {
+                            const real dij = sDij[jA * WI + iA];
 #pragma unroll
-                        for (int kk = 0; kk < CW; kk++)
+                            for (int kk = 0; kk < CW; kk++)
 #pragma unroll
-                            for (int cl = 0; cl < NFL; cl++) {
-                                const real v = acc[kk * NFL + cl];
-                                s += v * sDkl[(lbs + cl) * WK + kb + kk];
-                                jkl_acc[kk * NFL + cl] += (double)(v * dij);
-                            }
-                        lds_add(&sJij[jA * WI + iA], (double)s);
-                    }
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    const real v = acc[kk * NFL + cl];
+                                    s_ij += v * sDkl[(lbs + cl) * WK + kb + kk];
+                                    jkl_acc[kk * NFL + cl] += (double)(v * dij);
+                                }
+                        }
 #endif
 #if DO_K
-                    if (key_jk >= 0 && key_jk != nk_jk) {
-                        const int pk = (key_jk % TSK) * NFK + CH * CW;
-#pragma unroll
-                        for (int kk = 0; kk < CW; kk++) { lds_add(&sKjk[pjA * WK + pk + kk], kjk_acc[kk]); kjk_acc[kk] = 0; }
-                    }
-                    if (key_jl >= 0 && key_jl != nk_jl) {
-                        const int pl = (key_jl % TSL) * NFL;
-#pragma unroll
-                        for (int cl = 0; cl < NFL; cl++) { lds_add(&sKjl[pjA * WL + pl + cl], kjl_acc[cl]); kjl_acc[cl] = 0; }
-                    }
-                    key_jk = nk_jk;
-                    key_jl = nk_jl;
-                    pjA = jA;
-                    if (on) {
-                        real kil[NFL];
 #pragma unroll
                         for (int cl = 0; cl < NFL; cl++) kil[cl] = 0;
 #pragma unroll
                         for (int kk = 0; kk < CW; kk++) {
-                            real s_ik = 0, s_jk = 0;
+                            real sk = 0, s_jk = 0;
                             const real djk = sDjk[jA * WK + kb + kk], dik = sDik[iA * WK + kb + kk];
 #pragma unroll
                             for (int cl = 0; cl < NFL; cl++) {
                                 const real v = acc[kk * NFL + cl];
-                                s_ik += v * sDjl[jA * WL + lbs + cl];
+                                sk += v * sDjl[jA * WL + lbs + cl];
                                 s_jk += v * sDil[iA * WL + lbs + cl];
                                 kil[cl] += v * djk;
                                 kjl_acc[cl] += (double)(v * dik);
                             }
-                            lds_add(&sKik[iA * WK + kb + kk], (double)s_ik);
+                            s_ik[kk] = sk;
                             kjk_acc[kk] += (double)s_jk;
                         }
-#pragma unroll
-                        for (int cl = 0; cl < NFL; cl++) lds_add(&sKil[iA * WL + lbs + cl], (double)kil[cl]);
-                    }
 #endif
-                }
-                // final flush of the carried accumulators
+                        // ---- atomics of the step
 #if DO_J
-                if (key_kl >= 0) {
-                    const int pk = (key_kl / TSL) * NFK + CH * CW, pl = (key_kl % TSL) * NFL;
+                        lds_add(&sJij[jA * WI + iA], (double)s_ij);
+                        if (!keep_kl) {
 #pragma unroll
-                    for (int kk = 0; kk < CW; kk++)
+                            for (int kk = 0; kk < CW; kk++)
 #pragma unroll
-                        for (int cl = 0; cl < NFL; cl++) lds_add(&sJkl[(pl + cl) * WK + pk + kk], jkl_acc[kk * NFL + cl]);
-                }
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    lds_add(&sJkl[(lbs + cl) * WK + kb + kk], jkl_acc[kk * NFL + cl]);
+                                    jkl_acc[kk * NFL + cl] = 0;
+                                }
+                        }
 #endif
 #if DO_K
-                if (key_jk >= 0) {
-                    const int pk = (key_jk % TSK) * NFK + CH * CW;
 #pragma unroll
-                    for (int kk = 0; kk < CW; kk++) lds_add(&sKjk[pjA * WK + pk + kk], kjk_acc[kk]);
-                }
-                if (key_jl >= 0) {
-                    const int pl = (key_jl % TSL) * NFL;
+                        for (int kk = 0; kk < CW; kk++) lds_add(&sKik[iA * WK + kb + kk], (double)s_ik[kk]);
 #pragma unroll
-                    for (int cl = 0; cl < NFL; cl++) lds_add(&sKjl[pjA * WL + pl + cl], kjl_acc[cl]);
-                }
+                        for (int cl = 0; cl < NFL; cl++) lds_add(&sKil[iA * WL + lbs + cl], (double)kil[cl]);
+                        if (!keep_jk) {
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++) { lds_add(&sKjk[jA * WK + kb + kk], kjk_acc[kk]); kjk_acc[kk] = 0; }
+                        }
+                        if (!keep_jl) {
+#pragma unroll
+                            for (int cl = 0; cl < NFL; cl++) { lds_add(&sKjl[jA * WL + lbs + cl], kjl_acc[cl]); kjl_acc[cl] = 0; }
+                        }
 #endif
+                    }
+                }
             }
 #endif  // TILE_1Q
             STAMP(6);

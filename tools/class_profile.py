@@ -35,5 +35,5 @@ tot = sum(r[0] for r in rows)
 print(f"{name}: total serial kernel time {tot:.2f} ms, quartets {n64}, model GFLOP {sum(fl.values())/1e9:.1f}")
 for ms, ang, c, f in rows:
     print(f"  {ang}  {ms:8.3f} ms  quartets {c:9d}  GFLOP {f/1e9:8.3f}  TFLOP/s {f/ms/1e9:7.3f}  Mq/s {c/ms/1e3:8.1f}")
-os.makedirs("gpurun_out", exist_ok=True)
-json.dump([{"ang": a, "ms": m, "quartets": c, "flop": f} for m, a, c, f in rows], open("gpurun_out/class_profile.json", "w"))
+os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+json.dump([{"ang": a, "ms": m, "quartets": c, "flop": f} for m, a, c, f in rows], open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "class_profile.json"), "w"))
