@@ -90,9 +90,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # dry runs of the N-rank path on a one-GPU box: JQC_BENCH_BACKEND=gloo JQC_BENCH_ONE_DEVICE=1 (RCCL refuses two
+    # ranks on one device); the driver's multi-GPU runs use the defaults: one rank per GPU over RCCL
+    backend = os.environ.get("JQC_BENCH_BACKEND", "nccl")
+    if os.environ.get("JQC_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     mol, wname = load_workload(args.workload)
     layout = BasisLayout.from_mol(mol, alignment=tile_width)
@@ -154,7 +162,7 @@ def main():
                        "quartets_per_step": quartets, "model_gflop_per_step": flops_all / 1e9,
                        "whole_path_tflops": flops_all * args.steps / dt / 1e12,
                        "density": "rand(nao,nao) R R^T seed 9", "cutoff": 1e-13,
-                       "parallelism": f"quartet strips round-robin over {world} rank(s) + 1 Fock all-reduce"},
+                       "parallelism": f"quartet work sharded over {world} rank(s) (cost-aware class/strip split) + 1 Fock all-reduce"},
             "roofline": {"bound": "valu_fp64", "kernel": "jk_tile*_%d%d%d%d" % dom,
                          "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VALU_PEAK_TFLOPS if achieved else None,
