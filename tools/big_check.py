@@ -23,3 +23,29 @@ for it in range(3):
 n64, n32, per = g.quartet_counts()
 fl = sum(a * quartet_flops(ang, npr) for (ang, npr), (a, b) in per.items())
 print(f"  quartets {n64:.4e}  {n64/dt:.3e} q/s  model {fl/1e12:.3f} TFLOP -> {fl/dt/1e12:.2f} TFLOP/s  |vj|max {float(vj.abs().max()):.3e} finite {bool(torch.isfinite(vj).all() and torch.isfinite(vk).all())}")
+# ---- size-independent parity properties at full size (no CPU oracle finishes here in seconds):
+#  (1) launch geometry: ket chunks of 1 vs the default, no workgroup splits -> same J/K
+#  (2) independent algorithm: the queue-driven one-quartet-per-lane kernels (jk_1q1t.hip, direct global atomics)
+#  (3) symmetry of J and K for a symmetric density;  (4) linearity in the density
+if len(sys.argv) > 3 and sys.argv[3] == "check":
+    ref_j, ref_k = vj.clone(), vk.clone()
+    sc = float(max(ref_j.abs().max(), ref_k.abs().max()))
+    jkmod.KCHUNK_MAX, jkmod.NSPLIT_MAX = 1, 1
+    g2 = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
+    j2, k2 = g2(mol, dm, hermi=1)
+    print(f"  (1) kchunk=1 vs default:   dJ {float((j2-ref_j).abs().max())/sc:.2e}  dK {float((k2-ref_k).abs().max())/sc:.2e}  (relative to max element)")
+    jkmod.KCHUNK_MAX, jkmod.NSPLIT_MAX = 16, 8
+    os.environ["JQC_JK_ALGO"] = "1q1t"
+    from joltqc_amd.backend import jk as router
+    router.gen_jk_kernel.cache_clear()
+    t = time.time()
+    g3 = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
+    j3, k3 = g3(mol, dm, hermi=1); torch.cuda.synchronize()
+    print(f"  (2) queue 1q1t kernels ({time.time()-t:.1f}s incl. JIT): dJ {float((j3-ref_j).abs().max())/sc:.2e}  dK {float((k3-ref_k).abs().max())/sc:.2e}")
+    del os.environ["JQC_JK_ALGO"]; router.gen_jk_kernel.cache_clear()
+    print(f"  (3) asymmetry: J {float((ref_j-ref_j.T).abs().max())/sc:.2e}  K {float((ref_k-ref_k.T).abs().max())/sc:.2e}")
+    c2 = np.random.rand(mol.nao, nocc) - 0.5
+    dm2 = torch.from_numpy(c2 @ c2.T / nocc).cuda()
+    ja, ka = g(mol, dm2, hermi=1)
+    jb, kb = g(mol, dm + 0.5 * dm2, hermi=1)
+    print(f"  (4) linearity: J {float((jb-ref_j-0.5*ja).abs().max())/sc:.2e}  K {float((kb-ref_k-0.5*ka).abs().max())/sc:.2e}")
