@@ -176,7 +176,7 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
             _lib.check(L.jqc_dft_vxc(blk0, nblk, gcache.ngrids_pad, nrow.data_ptr(), base_d.data_ptr(), comp_stride,
                                      ws.data_ptr(), ao_idx.data_ptr(), w.data_ptr(), ndim, nao, vmat.data_ptr(), stream))
         _run(grids, 1 if ndim == 1 else 4, log_ao_cutoff - log_wv_max, body)
-        return layout.dm_to_mol(vmat)
+        return layout.dm_to_mol(vmat + vmat.T)          # the kernel accumulates T = phi X^T only (reference epilogue A + A^T, :654-655)
 
     def rks_fun(ni, mol, grids, xc_code, dm):
         """Incremental nr_rks (reference rks.py:308-364): returns (nelec, excsum, vxcmat)."""
