@@ -49,3 +49,14 @@ if len(sys.argv) > 3 and sys.argv[3] == "check":
     ja, ka = g(mol, dm2, hermi=1)
     jb, kb = g(mol, dm + 0.5 * dm2, hermi=1)
     print(f"  (4) linearity: J {float((jb-ref_j-0.5*ja).abs().max())/sc:.2e}  K {float((kb-ref_k-0.5*ka).abs().max())/sc:.2e}")
+    # (5) long-range (erf-attenuated) K with the tiled kernels vs the queue kernels; (6) mixed precision vs pure fp64
+    kj, kk = g(mol, dm, hermi=1, omega=0.3)
+    os.environ["JQC_JK_ALGO"] = "1q1t"; router.gen_jk_kernel.cache_clear()
+    g4 = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
+    qj, qk = g4(mol, dm, hermi=1, omega=0.3)
+    del os.environ["JQC_JK_ALGO"]; router.gen_jk_kernel.cache_clear()
+    print(f"  (5) omega=0.3 tiled vs queue: dJ {float((kj-qj).abs().max())/sc:.2e}  dK {float((kk-qk).abs().max())/sc:.2e}  |K_lr|max {float(kk.abs().max()):.3e}")
+    gm = jkmod.generate_jk_kernel(lay, cutoff_fp64=1e-7, cutoff_fp32=1e-13)
+    mj, mk = gm(mol, dm, hermi=1)
+    n64m, n32m, _ = gm.quartet_counts()
+    print(f"  (6) mixed 1e-13/1e-7 vs fp64: dJ {float((mj-ref_j).abs().max()):.2e}  dK {float((mk-ref_k).abs().max()):.2e} (absolute; reference bar 1e-7)  fp64 quartets {n64m:.3e} fp32 quartets {n32m:.3e}")
