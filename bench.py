@@ -41,6 +41,12 @@ def load_workload(name):
     from joltqc_amd.gto import mole
     if name == "benzene":
         return mole.Mole(atom=benzene_atoms(), basis="def2-tzvpp"), "benzene C6H6 RHF/def2-TZVPP J+K"
+    if name == "benzene-spdfg":
+        # artificial basis with every angular momentum up to g on every atom (the reference autotuner's test system,
+        # jqc/backend/data/generate_fragment.py:97-114): exercises all 140 angular classes
+        shells = [[0, [8.0, 0.2], [1.6, 0.5], [0.4, 0.4]], [0, [0.15, 1.0]], [1, [4.0, 0.3], [0.9, 0.5], [0.25, 0.4]],
+                  [2, [0.8, 1.0]], [3, [0.9, 1.0]], [4, [1.0, 1.0]]]
+        return mole.Mole(atom=benzene_atoms(), basis={"C": shells, "H": shells}), "benzene, artificial s/p/d/f/g basis"
     path = os.path.join(ROOT, "joltqc_amd", "data", "molecules", name + ".xyz")
     return mole.Mole(atom=mole.read_xyz(path), basis="def2-tzvpp"), f"{name} def2-TZVPP J+K"
 

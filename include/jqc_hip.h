@@ -33,6 +33,7 @@ extern "C" {
 #define JQC_VARIANT_RYS_L2 (1 << 8)    /* read the Rys table through L2 instead of staging it in LDS */
 #define JQC_VARIANT_ST1 (1 << 9)       /* single-buffered TRR array (less LDS, one more barrier per primitive combination) */
 #define JQC_VARIANT_WSYNC (1 << 10)    /* row-lane mode with every quartet inside one wave: no workgroup barrier per step */
+#define JQC_VARIANT_CJR (1 << 11)      /* row-lane mode, lane = bra component i only, the j components in registers (small kets) */
 
 const char* jqc_last_error(void);
 const char* jqc_version(void);

@@ -81,4 +81,10 @@ def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None
     ang = tuple(int(x) for x in ang)
     if algo is None:
         algo = select_algo(ang, fp32)
-    return _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, algo, compile_only)
+    try:
+        return _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, algo, compile_only)
+    except RuntimeError:
+        # a variant forced through JQC_JK_ALGO=v<code> may not exist for every class (LDS budget): plain row-lane kernel
+        if os.environ.get("JQC_JK_ALGO", "").lower().startswith("v") and (algo & 0xf) != _lib.ALGO_1Q1T:
+            return _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, _lib.ALGO_TILE, compile_only)
+        raise

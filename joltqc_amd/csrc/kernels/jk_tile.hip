@@ -49,7 +49,14 @@
 constexpr int ts_of(int l) { return l == 0 ? TSW0 : l == 1 ? TSW1 : l == 2 ? TSW2 : l == 3 ? TSW3 : TSW4; }
 constexpr int TSI = ts_of(LI), TSJ = ts_of(LJ), TSK = ts_of(LK), TSL = ts_of(LL);
 constexpr int NQ = TSI * TSJ * TSK * TSL;
-constexpr int T = NFI * NFJ;
+#ifndef CJR
+#define CJR 0       // row-lane mode with the bra j components in REGISTERS: lane = bra component ci only (T = nf_i lanes per
+                    // quartet), each lane runs the bra HRR for every cj and holds nf_j times more integrals.  For classes with a
+                    // small ket block (few integrals per (ci,cj) lane) the LDS reads of phase B are shared by nf_j times more
+                    // products and K_ik / K_il / J_ij need no cross-lane sum at all.
+#endif
+constexpr int EJ = CJR ? NFJ : 1;                    // bra j components held per lane
+constexpr int T = CJR ? NFI : NFI * NFJ;
 #ifndef TBLOCK
 #define TBLOCK 256   // threads per workgroup (512: two waves per SIMD share one set of LDS tiles; row-lane mode only)
 #endif
@@ -82,17 +89,25 @@ constexpr int G = WSYNC ? NWAVE * GW : TBLOCK / T;
 constexpr int pick_nch()
 {
     for (int n = 1; n <= NFK; n++)
-        if (NFK % n == 0 && (NFK / n) * NFL <= ECAP) return n;
+        if (NFK % n == 0 && (NFK / n) * NFL * EJ <= ECAP) return n;
     return NFK;
 }
 constexpr int NCH = pick_nch();
 constexpr int CW = NFK / NCH;
-constexpr int E = CW * NFL;
+constexpr int E = EJ * CW * NFL;                     // integrals per lane and chunk: e = (cj * CW + kk) * NFL + cl
 constexpr int WI = TSI * NFI, WJ = TSJ * NFJ, WK = TSK * NFK, WL = TSL * NFL;
 constexpr int NT2 = (LIJ + 1) * (LKL + 1);
 constexpr int NJOB = G * 3 * NROOTS;                                      // phase-A jobs per step
-constexpr int NBUF = (!WSYNC && 2 * G * NROOTS * 3 * NT2 * (int)sizeof(real) <= ST_LDS_MAX) ? 2 : 1;
+// The TRR array is single-buffered.  A double-buffered schedule (phase A of the next primitive combination issued before
+// phase B of the current one, one barrier per combination; code paths under NBUF > 1 below) measured 3-8 % faster, but it
+// gives wrong J/K in a few classes ((fd|fp), several g classes) on large inputs -- found by tools/verify_scheme.py, not
+// understood yet (no LDS race found by inspection; extra barriers do not cure it) -- so it stays disabled.
+#ifndef TRR_DOUBLE_BUFFER
+#define TRR_DOUBLE_BUFFER 0
+#endif
+constexpr int NBUF = (TRR_DOUBLE_BUFFER && !WSYNC && 2 * G * NROOTS * 3 * NT2 * (int)sizeof(real) <= ST_LDS_MAX) ? 2 : 1;
 static_assert(!WSYNC || (T <= 64 && !TILE_1Q), "WSYNC needs a quartet to fit one wave");
+static_assert(!CJR || !TILE_1Q, "CJR is a variant of the row-lane mode");
 #if WSYNC
 // ordering of LDS traffic inside one wave is kept by the hardware (one in-order DS queue per wave); the compiler only
 // has to keep the program order of the accesses
@@ -315,7 +330,11 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     const int slot = tid / T, t = tid - slot * T;
     const bool lane_on = slot < G;
 #endif
+#if CJR
+    const int ci = t, cj = 0;
+#else
     const int ci = t / NFJ, cj = t - ci * NFJ;
+#endif
     const int ibra[3] = {TI.x[ci], TI.y[ci], TI.z[ci]};
     const int jbra[3] = {TJ.x[cj], TJ.y[cj], TJ.z[cj]};
 #endif
@@ -670,13 +689,13 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma unroll
             for (int CH = 0; CH < NCH; CH++) {
                 // register accumulators carried across consecutive quartets of this lane that share the destination block
-                double jkl_acc[E], kjk_acc[CW], kjl_acc[NFL];
+                double jkl_acc[CW * NFL], kjk_acc[EJ * CW], kjl_acc[EJ * NFL];
 #pragma unroll
-                for (int e = 0; e < E; e++) jkl_acc[e] = 0;
+                for (int e = 0; e < CW * NFL; e++) jkl_acc[e] = 0;
 #pragma unroll
-                for (int n = 0; n < CW; n++) kjk_acc[n] = 0;
+                for (int n = 0; n < EJ * CW; n++) kjk_acc[n] = 0;
 #pragma unroll
-                for (int n = 0; n < NFL; n++) kjl_acc[n] = 0;
+                for (int n = 0; n < EJ * NFL; n++) kjl_acc[n] = 0;
 
                 int item = 0;
                 if (NBUF > 1) {
@@ -738,6 +757,52 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma clang loop unroll(disable)
 #endif
                             for (int r = 0; r < NROOTS; r++) {
+#if CJR
+                                // bra HRR for every j power and the ket HRR in registers: gk[axis][j][k][l]
+                                real gk[3][LJ + 1][LK + 1][LL + 1];
+#pragma unroll
+                                for (int ax = 0; ax < 3; ax++) {
+                                    const real* tp = myT + (r * 3 + ax) * NT2 + ibra[ax] * (LKL + 1);
+                                    real h[LJ + 1][LKL + 1];
+#pragma unroll
+                                    for (int m = 0; m <= LJ; m++)
+#pragma unroll
+                                        for (int cc = 0; cc <= LKL; cc++) h[m][cc] = tp[m * (LKL + 1) + cc];
+#pragma unroll
+                                    for (int j = 0; j <= LJ; j++) {
+                                        real w[LKL + 1];
+#pragma unroll
+                                        for (int cc = 0; cc <= LKL; cc++) w[cc] = h[0][cc];
+#pragma unroll
+                                        for (int l = 0; l <= LL; l++) {
+#pragma unroll
+                                            for (int k = 0; k <= LK; k++) gk[ax][j][k][l] = w[k];
+                                            if (l < LL) {
+#pragma unroll
+                                                for (int cc = 0; cc < LKL - l; cc++) w[cc] = w[cc + 1] - rkl[ax] * w[cc];
+                                            }
+                                        }
+                                        if (j < LJ) {
+#pragma unroll
+                                            for (int m = 0; m < LJ - j; m++)
+#pragma unroll
+                                                for (int cc = 0; cc <= LKL; cc++) h[m][cc] = h[m + 1][cc] - rij[ax] * h[m][cc];
+                                        }
+                                    }
+                                }
+#pragma unroll
+                                for (int oj = 0; oj < NFJ; oj++)
+#pragma unroll
+                                    for (int kk = 0; kk < CW; kk++)
+#pragma unroll
+                                        for (int cl = 0; cl < NFL; cl++) {
+                                            const int ck = CH * CW + kk;
+                                            acc[(oj * CW + kk) * NFL + cl] += gk[0][TJ.x[oj]][TK.x[ck]][TL.x[cl]] *
+                                                                              gk[1][TJ.y[oj]][TK.y[ck]][TL.y[cl]] *
+                                                                              gk[2][TJ.z[oj]][TK.z[ck]][TL.z[cl]];
+                                        }
+                            }
+#else
                                 real gk[3][LK + 1][LL + 1];
 #pragma unroll
                                 for (int ax = 0; ax < 3; ax++) {
@@ -768,6 +833,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                                               gk[2][TK.z[ck]][TL.z[cl]];
                                     }
                             }
+#endif
                         }
                         STAMP(11);
                         STEP_SYNC();
@@ -790,6 +856,89 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         keep_jk = b2 == b && c2 == c;
                         keep_jl = b2 == b && d2 == d;
                     }
+#if CJR
+                    if (on) {
+                        // lane = bra component ci, registers = (cj, k, l): J_ij, K_ik, K_il are complete in the lane
+                        const int jA0 = b * NFJ;
+                        real s_ij[NFJ], s_ik[CW], s_il[NFL];
+#pragma unroll
+                        for (int kk = 0; kk < CW; kk++) s_ik[kk] = 0;
+#pragma unroll
+                        for (int cl = 0; cl < NFL; cl++) s_il[cl] = 0;
+#pragma unroll
+                        for (int oj = 0; oj < NFJ; oj++) {
+                            real sj = 0;
+#if DO_J
+                            const real dij = sDij[(jA0 + oj) * WI + iA];
+#endif
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++) {
+#if DO_K
+                                const real djk = sDjk[(jA0 + oj) * WK + kb + kk], dik = sDik[iA * WK + kb + kk];
+                                real s_jk = 0;
+#endif
+#pragma unroll
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    const real v = acc[(oj * CW + kk) * NFL + cl];
+#if DO_J
+                                    sj += v * sDkl[(lbs + cl) * WK + kb + kk];
+                                    jkl_acc[kk * NFL + cl] += (double)(v * dij);
+#endif
+#if DO_K
+                                    s_ik[kk] += v * sDjl[(jA0 + oj) * WL + lbs + cl];
+                                    s_il[cl] += v * djk;
+                                    s_jk += v * sDil[iA * WL + lbs + cl];
+                                    kjl_acc[oj * NFL + cl] += (double)(v * dik);
+#endif
+                                }
+#if DO_K
+                                kjk_acc[oj * CW + kk] += (double)s_jk;
+#endif
+                            }
+                            s_ij[oj] = sj;
+                        }
+                        // ---- atomics of the step
+#if DO_J
+#pragma unroll
+                        for (int oj = 0; oj < NFJ; oj++) lds_add(&sJij[(jA0 + oj) * WI + iA], (double)s_ij[oj]);
+                        if (!keep_kl) {
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++)
+#pragma unroll
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    lds_add(&sJkl[(lbs + cl) * WK + kb + kk], jkl_acc[kk * NFL + cl]);
+                                    jkl_acc[kk * NFL + cl] = 0;
+                                }
+                        }
+#endif
+#if DO_K
+#pragma unroll
+                        for (int kk = 0; kk < CW; kk++) lds_add(&sKik[iA * WK + kb + kk], (double)s_ik[kk]);
+#pragma unroll
+                        for (int cl = 0; cl < NFL; cl++) lds_add(&sKil[iA * WL + lbs + cl], (double)s_il[cl]);
+                        if (!keep_jk) {
+#pragma unroll
+                            for (int oj = 0; oj < NFJ; oj++)
+#pragma unroll
+                                for (int kk = 0; kk < CW; kk++) {
+                                    lds_add(&sKjk[(jA0 + oj) * WK + kb + kk], kjk_acc[oj * CW + kk]);
+                                    kjk_acc[oj * CW + kk] = 0;
+                                }
+                        }
+                        if (!keep_jl) {
+#pragma unroll
+                            for (int oj = 0; oj < NFJ; oj++)
+#pragma unroll
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    lds_add(&sKjl[(jA0 + oj) * WL + lbs + cl], kjl_acc[oj * NFL + cl]);
+                                    kjl_acc[oj * NFL + cl] = 0;
+                                }
+                        }
+#endif
+                    }
+                }
+            }
+#else
                     real s_ij = 0, s_ik[CW], kil[NFL];
                     if (on) {
 #if DO_J
@@ -854,6 +1003,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     }
                 }
             }
+#endif  // CJR
 #endif  // TILE_1Q
             STAMP(6);
             __syncthreads();

@@ -171,7 +171,8 @@ def test_ket_chunks_and_workgroup_splits(monkeypatch):
         assert n64 == len(dense.canonical_quartets(lay))
 
 
-@pytest.mark.parametrize("variant", [0x11, 0x21 | 0x100, 0x11 | 0x400, 0x21 | 0x100 | 0x200, 0x12, 0x32])
+@pytest.mark.parametrize("variant", [0x11, 0x21 | 0x100, 0x11 | 0x400, 0x21 | 0x100 | 0x200, 0x12, 0x32, 0x11 | 0x800,
+                                     0x21 | 0x100 | 0x800])
 def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
     """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
     L2 | single TRR buffer | wave-local steps; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.

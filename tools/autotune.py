@@ -15,12 +15,14 @@ AVAIL = os.path.join(CACHE, "available.json")
 os.environ["JQC_KERNEL_CACHE"] = CACHE
 
 MINW = lambda n: n << 4
-RYS_L2, ST1, WSYNC = 1 << 8, 1 << 9, 1 << 10
+RYS_L2, ST1, WSYNC, CJR = 1 << 8, 1 << 9, 1 << 10, 1 << 11
 CANDIDATES = [2 | MINW(1), 2 | MINW(2), 2 | MINW(3),
               1 | MINW(1), 1 | MINW(2), 1 | MINW(1) | RYS_L2, 1 | MINW(2) | RYS_L2, 1 | MINW(2) | RYS_L2 | ST1,
               1 | MINW(3) | RYS_L2 | ST1,
               1 | MINW(1) | WSYNC, 1 | MINW(2) | WSYNC, 1 | MINW(1) | RYS_L2 | WSYNC, 1 | MINW(2) | RYS_L2 | WSYNC,
-              1 | MINW(3) | RYS_L2 | WSYNC]
+              1 | MINW(3) | RYS_L2 | WSYNC,
+              1 | MINW(1) | CJR, 1 | MINW(1) | RYS_L2 | CJR, 1 | MINW(2) | RYS_L2 | CJR, 1 | MINW(2) | RYS_L2 | ST1 | CJR,
+              1 | MINW(3) | RYS_L2 | ST1 | CJR]
 if os.environ.get("JQC_TUNE_ONLY"):
     CANDIDATES = [int(x, 0) for x in os.environ["JQC_TUNE_ONLY"].split(",")]
 MAX_1Q = 200
@@ -102,18 +104,22 @@ def run(workload):
 
 
 def merge(files):
-    """Best variant per class; the first file decides, later files only fill classes the first lacks."""
+    """Best variant per class; the first file decides, later files only fill classes the first lacks.  Variants listed
+    under "rejected" in the scheme file (they failed tools/verify_scheme.py at full size) are never chosen."""
+    path = os.path.join(ROOT, "joltqc_amd", "data", "gfx950_scheme.json")
+    rejected = {k: set(v) for k, v in json.load(open(path)).get("rejected", {}).items()}
     best = {}
     for f in files:
         data = json.load(open(f))
         per = {}
         for v, tm in data.items():
             for key, ms in tm.items():
+                if int(v) in rejected.get(key, ()):
+                    continue
                 if key not in per or ms < per[key][1]:
                     per[key] = (int(v), ms)
         for key, (v, ms) in per.items():
             best.setdefault(key, v)
-    path = os.path.join(ROOT, "joltqc_amd", "data", "gfx950_scheme.json")
     old = json.load(open(path))
     for prec in ("fp64", "fp32"):
         for ang in classes(4):
