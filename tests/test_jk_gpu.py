@@ -261,3 +261,41 @@ def test_two_ranks_share_the_quartets_and_allreduce_the_fock_matrix():
     n_all, _, _ = get_jk.quartet_counts()
     assert res[0][3] + res[1][3] == n_all          # every dispatched quartet on exactly one rank
     assert min(res[0][3], res[1][3]) > 0.25 * n_all
+
+
+def test_every_angular_class_against_the_oracle():
+    """All 140 angular classes s..g, CLASS BY CLASS: the kernel the scheme table selects for the class vs the CPU oracle
+    restricted to the quartets of that class (three atoms, artificial s/p/d/f/g basis, the reference autotuner's kind of
+    test system, jqc/backend/data/generate_fragment.py:97-114).  A miscompiled or racy class kernel shows up here even when
+    the common molecules never reach it ((gg|fp) did)."""
+    import os
+    from joltqc_amd.pyscf import jk as jkmod
+    from oracle import dense
+    shells = [[0, [8.0, 0.2], [1.6, 0.5], [0.4, 0.4]], [0, [0.15, 1.0]], [1, [4.0, 0.3], [0.9, 0.5], [0.25, 0.4]],
+              [2, [0.8, 1.0]], [3, [0.9, 1.0]], [4, [1.0, 1.0]]]
+    mol, lay, _ = _setup("C 0 0 0; C 0 0.3 2.4; H 1.5 0.2 0.9", {"C": shells, "H": shells}, unit="B")
+    dm = _dm(mol.nao)
+    allq = dense.canonical_quartets(lay)
+    qa = np.asarray(lay.angs)[allq.astype(int)]
+    bad, nclass = [], 0
+    try:
+        for li in range(5):
+            for lj in range(li + 1):
+                for lk in range(li + 1):
+                    for ll in range(lk + 1):
+                        sel = (qa == np.array([li, lj, lk, ll])).all(1)
+                        if not sel.any():
+                            continue
+                        nclass += 1
+                        key = "%d%d%d%d" % (li, lj, lk, ll)
+                        rj, rk = dense.get_jk(lay, dm, hermi=1, quartets=allq[sel])
+                        os.environ["JQC_ONLY_CLASS"] = key
+                        get_jk = jkmod.generate_jk_kernel(lay, cutoff_fp64=1e-13, cutoff_fp32=1e-13)
+                        vj, vk = get_jk(mol, dm, hermi=1)
+                        sc = max(np.abs(rj).max(), np.abs(rk).max())
+                        err = max(np.abs(_np(vj) - rj).max(), np.abs(_np(vk) - rk).max()) / sc
+                        if err > 1e-11 or get_jk.quartet_counts()[0] != int(sel.sum()):
+                            bad.append((key, err))
+    finally:
+        os.environ.pop("JQC_ONLY_CLASS", None)
+    assert nclass == 140 and not bad, bad

@@ -18,7 +18,7 @@ np.random.seed(9)
 dm = np.random.rand(mol.nao, mol.nao); dm = torch.from_numpy(dm @ dm.T).cuda()
 angs = sorted(set(int(a) for a in lay.angs))
 classes = [(a, b, c, d) for a in angs for b in angs for c in angs for d in angs if a >= b and a >= c and c >= d]
-REF = 0x211          # row-lane, 1 wave/SIMD budget, Rys table through L2, single TRR buffer
+REF = 0x221          # row-lane, <= 256 VGPRs (no AGPR spill space), Rys table through L2, single TRR buffer
 out, bad = {}, []
 for ang in classes:
     key = "%d%d%d%d" % ang
