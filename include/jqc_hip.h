@@ -31,7 +31,7 @@ extern "C" {
 /* Tuning variant of a tiled kernel, OR-ed into the `algo` argument of jqc_gen_jk_kernel (gfx950 scheme table): */
 #define JQC_VARIANT_MINW(n) ((n) << 4) /* waves per SIMD the register allocation leaves room for (0 = kernel default) */
 #define JQC_VARIANT_RYS_L2 (1 << 8)    /* read the Rys table through L2 instead of staging it in LDS */
-#define JQC_VARIANT_ST1 (1 << 9)       /* single-buffered TRR array (less LDS, one more barrier per primitive combination) */
+#define JQC_VARIANT_ST1 (1 << 9)       /* single-buffered TRR array; no effect while the double buffer is disabled (jk_tile.hip) */
 #define JQC_VARIANT_WSYNC (1 << 10)    /* row-lane mode with every quartet inside one wave: no workgroup barrier per step */
 #define JQC_VARIANT_CJR (1 << 11)      /* row-lane mode, lane = bra component i only, the j components in registers (small kets) */
 
