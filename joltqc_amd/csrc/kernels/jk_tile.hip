@@ -78,7 +78,8 @@ constexpr int G = WSYNC ? NWAVE * GW : TBLOCK / T;
 #define RYS_LDS_MAX 28672   // stage the class's Chebyshev table in LDS when it is at most this many bytes (nroots <= 5 in f64)
 #endif
 #ifndef MINW
-#define MINW (TILE_1Q ? 2 : 1)   // waves/SIMD the register allocator leaves room for
+#define MINW 2      // waves/SIMD the register allocator leaves room for.  Never 1: builds with more than 256 registers per lane
+                    // (AGPR spill space) gave wrong results in a few classes (tools/verify_scheme.py)
 #endif
 #ifndef UNROLL_B
 #define UNROLL_B 1   // 1: unroll the root loop of phase B (loads of root r+1 overlap the products of root r)

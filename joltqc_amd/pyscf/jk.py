@@ -503,6 +503,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                 if state["streams"] is None or len(state["streams"]) != state["nstreams"]:
                     state["streams"] = [torch.cuda.Stream(device=dev) for _ in range(state["nstreams"])]
                 side = state["streams"]
+                if mixed:
+                    tt.pair_tab32()            # created on the current stream BEFORE the side streams fork from it
                 cur = torch.cuda.current_stream()
                 ev = torch.cuda.Event()
                 ev.record(cur)

@@ -171,7 +171,7 @@ def test_ket_chunks_and_workgroup_splits(monkeypatch):
         assert n64 == len(dense.canonical_quartets(lay))
 
 
-@pytest.mark.parametrize("variant", [0x11, 0x21 | 0x100, 0x11 | 0x400, 0x21 | 0x100 | 0x200, 0x12, 0x32, 0x11 | 0x800,
+@pytest.mark.parametrize("variant", [0x21, 0x21 | 0x100, 0x21 | 0x400, 0x21 | 0x100 | 0x400, 0x22, 0x32, 0x21 | 0x800,
                                      0x21 | 0x100 | 0x800])
 def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
     """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
@@ -263,11 +263,13 @@ def test_two_ranks_share_the_quartets_and_allreduce_the_fock_matrix():
     assert min(res[0][3], res[1][3]) > 0.25 * n_all
 
 
-def test_every_angular_class_against_the_oracle():
+@pytest.mark.parametrize("mode", ["jk", "j", "k", "lr", "fp32"])
+def test_every_angular_class_against_the_oracle(mode):
     """All 140 angular classes s..g, CLASS BY CLASS: the kernel the scheme table selects for the class vs the CPU oracle
     restricted to the quartets of that class (three atoms, artificial s/p/d/f/g basis, the reference autotuner's kind of
-    test system, jqc/backend/data/generate_fragment.py:97-114).  A miscompiled or racy class kernel shows up here even when
-    the common molecules never reach it ((gg|fp) did)."""
+    test system, jqc/backend/data/generate_fragment.py:97-114) -- for each of the five builds of a class kernel: J+K,
+    J only, K only, long-range (omega = 0.3) and fp32.  A miscompiled or racy class kernel shows up here even when the
+    common molecules never reach it ((gg|fp) did)."""
     import os
     from joltqc_amd.pyscf import jk as jkmod
     from oracle import dense
@@ -277,6 +279,9 @@ def test_every_angular_class_against_the_oracle():
     dm = _dm(mol.nao)
     allq = dense.canonical_quartets(lay)
     qa = np.asarray(lay.angs)[allq.astype(int)]
+    with_j, with_k = mode != "k", mode != "j"
+    omega = 0.3 if mode == "lr" else None
+    cut64, tol = (1e100, 2e-5) if mode == "fp32" else (1e-13, 1e-11)      # fp32: every quartet through the fp32 kernels
     bad, nclass = [], 0
     try:
         for li in range(5):
@@ -288,14 +293,15 @@ def test_every_angular_class_against_the_oracle():
                             continue
                         nclass += 1
                         key = "%d%d%d%d" % (li, lj, lk, ll)
-                        rj, rk = dense.get_jk(lay, dm, hermi=1, quartets=allq[sel])
+                        rj, rk = dense.get_jk(lay, dm, hermi=1, quartets=allq[sel], omega=omega, with_j=with_j, with_k=with_k)
                         os.environ["JQC_ONLY_CLASS"] = key
-                        get_jk = jkmod.generate_jk_kernel(lay, cutoff_fp64=1e-13, cutoff_fp32=1e-13)
-                        vj, vk = get_jk(mol, dm, hermi=1)
-                        sc = max(np.abs(rj).max(), np.abs(rk).max())
-                        err = max(np.abs(_np(vj) - rj).max(), np.abs(_np(vk) - rk).max()) / sc
-                        if err > 1e-11 or get_jk.quartet_counts()[0] != int(sel.sum()):
-                            bad.append((key, err))
+                        get_jk = jkmod.generate_jk_kernel(lay, cutoff_fp64=cut64, cutoff_fp32=1e-13)
+                        vj, vk = get_jk(mol, dm, hermi=1, with_j=with_j, with_k=with_k, omega=omega)
+                        sc = max(np.abs(rj).max() if with_j else 0.0, np.abs(rk).max() if with_k else 0.0)
+                        err = max(np.abs(_np(vj) - rj).max() if with_j else 0.0, np.abs(_np(vk) - rk).max() if with_k else 0.0) / sc
+                        n64, n32, _ = get_jk.quartet_counts()
+                        if not err < tol or n64 + n32 != int(sel.sum()):
+                            bad.append((key, err, n64 + n32, int(sel.sum())))
     finally:
         os.environ.pop("JQC_ONLY_CLASS", None)
     assert nclass == 140 and not bad, bad

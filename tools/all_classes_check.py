@@ -31,12 +31,13 @@ for li in range(5):
                 sel = (qa == np.array([li, lj, lk, ll])).all(1)
                 if not sel.any():
                     continue
-                rj, rk = dense.get_jk(lay, dm, hermi=1, quartets=allq[sel])
+                om = 0.3 if os.environ.get("JQC_CHECK_MODE") == "lr" else None
+                rj, rk = dense.get_jk(lay, dm, hermi=1, quartets=allq[sel], omega=om)
                 os.environ["JQC_ONLY_CLASS"] = key
                 g = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
                 errs = []
                 for rep in range(2):
-                    vj, vk = g(mol, dm, hermi=1)
+                    vj, vk = g(mol, dm, hermi=1, omega=om)
                     sc = max(np.abs(rj).max(), np.abs(rk).max(), 1e-300)
                     errs.append(max(np.abs(vj.cpu().numpy() - rj).max(), np.abs(vk.cpu().numpy() - rk).max()) / sc)
                 n = g.quartet_counts()[0]

@@ -103,6 +103,16 @@ def run(workload):
     json.dump(out, open(f"gpurun_out/autotune_{workload}.json", "w"))
 
 
+def allowed(v):
+    """Builds the scheme table may use.  Excluded: one-wave-per-SIMD builds (up to 512 registers per lane: 256 VGPRs + AGPR
+    spill space) and three-waves-per-SIMD builds of the row-lane kernels (168 VGPRs, heavy scratch spilling).  Every
+    wrong-result kernel build found in round 1 ((gg|fp), the long-range builds of (fp|ff) and (ff|fs)) was one of these,
+    the same source being correct at two waves per SIMD; the measured cost of the exclusion is 2.5 %
+    (profiles/r01_autotune_last_run.json).  The lane-per-quartet kernels at three waves per SIMD pass every gate."""
+    minw = (v >> 4) & 0xf
+    return minw != 1 and not ((v & 0xf) == 1 and minw == 3)
+
+
 def merge(files):
     """Best variant per class; the first file decides, later files only fill classes the first lacks.  Variants listed
     under "rejected" in the scheme file (they failed tools/verify_scheme.py at full size) are never chosen."""
@@ -114,7 +124,7 @@ def merge(files):
         per = {}
         for v, tm in data.items():
             for key, ms in tm.items():
-                if int(v) in rejected.get(key, ()):
+                if int(v) in rejected.get(key, ()) or not allowed(int(v)):
                     continue
                 if key not in per or ms < per[key][1]:
                     per[key] = (int(v), ms)
