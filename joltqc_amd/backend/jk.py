@@ -22,6 +22,15 @@ def _table():
     return {}
 
 
+def fp32_pays(ang):
+    """Mixed precision: does the fp32 kernel of class ``ang`` beat the fp64 one per quartet on this chip?  Measured table
+    (gfx950_scheme.json "fp32_pays", tools/autotune.py with JQC_TUNE_FP32=1); JQC_FP32_WINDOW=1/0 forces the answer."""
+    force = os.environ.get("JQC_FP32_WINDOW")
+    if force is not None:
+        return force == "1"
+    return bool(_table().get("fp32_pays", {}).get(class_key(ang), True))
+
+
 def class_cost_table():
     """{class key: measured ns per dispatched quartet} (gfx950_scheme.json, tools/class_profile.py)."""
     return _table().get("ns_per_quartet", {})

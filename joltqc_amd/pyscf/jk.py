@@ -409,6 +409,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
     log_cutoff_fp64 = float(np.float32(math.log(cutoff_fp64)))
     log_cutoff_fp32 = float(np.float32(math.log(cutoff_fp32)))
     mixed = cutoff_fp32 < cutoff_fp64
+    fp32_only = cutoff_fp64 >= 1e30          # an explicit all-fp32 request (reference tests use 1e100) is always honoured
     layout = basis_layout
     nbas = layout.nbasis
     nao = layout.nao
@@ -526,18 +527,19 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     if probing:
                         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         ev0.record(sid)
+                    # mixed precision: quartets with estimate in (cutoff_fp32, cutoff_fp64] go to the fp32 kernel of the class
+                    # -- where that kernel is measured faster per quartet than the fp64 one (gfx950_scheme.json "fp32_pays");
+                    # elsewhere the fp64 kernel takes both windows in ONE launch (more accurate and, on this chip, faster:
+                    # two launches stage and screen every tile pair twice)
+                    split = mixed and (fp32_only or _router.fp32_pays(ang))
                     _lib.check(L.jqc_jk_tile_launch(h64, nao, b64.data_ptr(), dms.data_ptr(), vj_p, vk_p, om,
                                                     tabs_d.data_ptr() + row * 32, tab.shape[0], nblk, tt.sh.data_ptr(),
                                                     tt.q.data_ptr(), tt.q_dev.data_ptr(), log_dm_cond.data_ptr(), nbas,
-                                                    log_cutoff_fp64 if mixed else log_cutoff_fp32, INF, log_max_dm, n_dm,
+                                                    log_cutoff_fp64 if split else log_cutoff_fp32, INF, log_max_dm, n_dm,
                                                     tile_counts[0].data_ptr(), idx_p, tt.ao.data_ptr(), tt.pp_off.data_ptr(),
                                                     tt.pair_tab.data_ptr(), sp))
-                    if probing:
-                        ev1.record(sid)
-                        state["stats"].setdefault("probe_events", []).append((ev0, ev1))
-                        state["stats"].setdefault("probe_classes", []).append(tuple(ang))
                     n_launch += 1
-                    if mixed:
+                    if split:
                         h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True,
                                                     algo=_router.select_algo(ang, True))
                         _lib.check(L.jqc_jk_tile_launch(h32, nao, b32.data_ptr(), dms_fp32.data_ptr(), vj_p, vk_p, om,
@@ -547,6 +549,10 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                                                         log_max_dm, n_dm, tile_counts[1].data_ptr(), idx_p, tt.ao.data_ptr(), tt.pp_off.data_ptr(),
                                                         tt.pair_tab32().data_ptr(), sp))
                         n_launch += 1
+                    if probing:
+                        ev1.record(sid)
+                        state["stats"].setdefault("probe_events", []).append((ev0, ev1))
+                        state["stats"].setdefault("probe_classes", []).append(tuple(ang))
                     row += tab.shape[0]
                 for st_ in side:
                     e2 = torch.cuda.Event()

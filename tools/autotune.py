@@ -39,11 +39,14 @@ def classes(lmax=3):
     return [(a, b, c, d) for a in range(lmax + 1) for b in range(a + 1) for c in range(a + 1) for d in range(c + 1)]
 
 
+FP32 = int(os.environ.get("JQC_TUNE_FP32", "0"))     # 1: tune the fp32 kernels (every quartet through them)
+
+
 def _compile(job):
     from joltqc_amd.backend import lib as L
     ang, v = job
     try:
-        L.gen_jk_kernel(ang, 1, 1, 0, 0, v, compile_only=True)
+        L.gen_jk_kernel(ang, 1, 1, 0, FP32, v, compile_only=True)
         return (ang, v, True)
     except Exception:  # noqa: BLE001  (LDS overflow of a variant is an expected outcome)
         return (ang, v, False)
@@ -84,8 +87,9 @@ def run(workload):
     for v in CANDIDATES:
         state["v"] = v
         # classes the variant does not exist for are skipped (select -> untimed default kernel)
-        router.select_algo = lambda ang, fp32=False: (forced(ang) if forced(ang) >= 0 else default(ang, fp32))
-        g = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
+        router.select_algo = lambda ang, fp32=False: (forced(ang) if (forced(ang) >= 0 and bool(fp32) == bool(FP32))
+                                                      else default(ang, fp32))
+        g = jkmod.generate_jk_kernel(lay, 1e100 if FP32 else 1e-13, 1e-13)
         g(mol, dm, hermi=1)
         torch.cuda.synchronize()
         g.set_probe("all")
@@ -100,7 +104,7 @@ def run(workload):
         out[str(v)] = tm
         print(f"variant {v:#x}: {len(tm)} classes, sum {sum(tm.values()):.1f} ms", flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(out, open(f"gpurun_out/autotune_{workload}.json", "w"))
+    json.dump(out, open(f"gpurun_out/autotune_{workload}{'_fp32' if FP32 else ''}.json", "w"))
 
 
 def allowed(v):
