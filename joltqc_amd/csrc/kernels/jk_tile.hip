@@ -219,6 +219,28 @@ __device__ __forceinline__ void lds_add(double* p, double v) { atomicAdd(p, v); 
 #ifndef KNAME
 #define KNAME jk_tile
 #endif
+// The kernel arguments as they lie in the kernarg segment (same order / natural alignment as the signature below).
+// The ket loop re-reads the pointers it needs from there (scalar loads, K$ hits) at the start of its staging and
+// flush sections instead of keeping ~15 pointers + scalars live in SGPRs across the compute phase: the compute
+// phase is what runs out of SGPRs (exec-mask stack + uniform loop state), and every SGPR held for the staging code
+// is one more spilled to a VGPR lane there.
+#ifndef KARG_RELOAD
+#define KARG_RELOAD 1
+#endif
+#define AS4 __attribute__((address_space(4)))
+struct KArgs {
+    int nao; const real* basis; const real* dm; double* vj; double* vk; real omega; const int* tasks; int ntasks;
+    const unsigned* tpair_sh; const float* tpair_q; const float* q_cond; const float* log_dm; int nbas;
+    float cut_lo, cut_hi, log_max_dm; int n_dm; const real* rys_cheb; const real* rys_large;
+    unsigned long long* counter; const int* blk_index; const unsigned* tpair_ao; const unsigned* tpair_pp;
+    const real* pair_tab;
+};
+__device__ __forceinline__ const KArgs AS4* kargs()
+{
+    const KArgs AS4* p = (const KArgs AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));          // opaque: the loads below it stay where they are written
+    return p;
+}
 extern "C" __global__ void __launch_bounds__(TBLOCK, MINW)
 KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm, double* __restrict__ vj,
         double* __restrict__ vk, const real omega, const int* __restrict__ tasks, const int ntasks,
@@ -343,11 +365,20 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     unsigned nq_done = 0;
     int parity = 0;
 
+#if KARG_RELOAD
+    for (int idm = 0; idm < kargs()->n_dm; idm++) {
+#else
     for (int idm = 0; idm < n_dm; idm++) {
         const real* __restrict__ D = dm + idm * nao2;
+#endif
 #if DO_J
         __syncthreads();
         {
+#if KARG_RELOAD
+            const KArgs AS4* kd = kargs();
+            const int nao = kd->nao;
+            const real* __restrict__ D = kd->dm + idm * ((size_t)nao * nao);
+#endif
             TileRegs<WJ, WI> r;
             tile_load(r, D, nao, j0, i0, tid);
             tile_store(sDij, r, tid);
@@ -355,6 +386,20 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         STAMP(2);
 #endif
         for (int kt = kt0; kt < kt1; kt++) {
+#if KARG_RELOAD
+            const KArgs AS4* ka = kargs();
+            const int nao = ka->nao, nbas = ka->nbas;
+            const float cut_lo = ka->cut_lo, cut_hi = ka->cut_hi;
+            const unsigned* __restrict__ tpair_sh = ka->tpair_sh;
+            const unsigned* __restrict__ tpair_ao = ka->tpair_ao;
+            const unsigned* __restrict__ tpair_pp = ka->tpair_pp;
+            const float* __restrict__ tpair_q = ka->tpair_q;
+            const float* __restrict__ q_cond = ka->q_cond;
+            const float* __restrict__ log_dm = ka->log_dm;
+            const real* __restrict__ basis = ka->basis;
+            const real* __restrict__ pair_tab = ka->pair_tab;
+            const real* __restrict__ D = ka->dm + idm * ((size_t)nao * nao);
+#endif
             const unsigned pkl = tpair_sh[kl0 + kt], aokl = tpair_ao[kl0 + kt];
             if (qij + tpair_q[kl0 + kt] <= cut_lo) break;
             const int ksh0 = pkl >> 16, lsh0 = pkl & 0xffff;
@@ -1012,7 +1057,15 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             int tid_f = tid;
             asm volatile("" : "+v"(tid_f));
 #define tid tid_f
+            {
             // ---- ket-dependent Fock sub-blocks of this tile pair: one coalesced pass of global f64 atomics each
+#if KARG_RELOAD
+            const KArgs AS4* kf = kargs();
+            const int nao = kf->nao;
+            const size_t nao2 = (size_t)nao * nao;
+            double* __restrict__ vj = kf->vj;
+            double* __restrict__ vk = kf->vk;
+#endif
 #if DO_J
             flush_tile(sJkl, vj + idm * nao2, nao, l0, k0, WL, WK, tid);
 #endif
@@ -1025,12 +1078,21 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 flush_tile(sKjl, K, nao, j0, l0, WJ, WL, tid);
             }
 #endif
+            }
 #undef tid
             STAMP(8);
         }
 #if DO_J
         __syncthreads();
-        flush_tile(sJij, vj + idm * nao2, nao, j0, i0, WJ, WI, tid);   // J_ij: summed over the whole ket chunk
+        {
+#if KARG_RELOAD
+            const KArgs AS4* kf = kargs();
+            const int nao = kf->nao;
+            const size_t nao2 = (size_t)nao * nao;
+            double* __restrict__ vj = kf->vj;
+#endif
+            flush_tile(sJij, vj + idm * nao2, nao, j0, i0, WJ, WI, tid);   // J_ij: summed over the whole ket chunk
+        }
 #endif
         STAMP(9);
     }
@@ -1040,5 +1102,13 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         atomicAdd(counter - 16, 1ull);
     }
 #endif
+#if KARG_RELOAD
+    {
+        const KArgs AS4* ke = kargs();
+        unsigned long long* cnt = ke->counter;
+        if (tid == 0 && cnt && nq_done) atomicAdd(cnt + ke->tasks[row * 8 + 6], (unsigned long long)nq_done);
+    }
+#else
     if (tid == 0 && counter && nq_done) atomicAdd(counter + tk[6], (unsigned long long)nq_done);   // per task row (slot 6)
+#endif
 }
