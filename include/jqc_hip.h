@@ -34,6 +34,8 @@ extern "C" {
 #define JQC_VARIANT_ST1 (1 << 9)       /* single-buffered TRR array; no effect while the double buffer is disabled (jk_tile.hip) */
 #define JQC_VARIANT_WSYNC (1 << 10)    /* row-lane mode with every quartet inside one wave: no workgroup barrier per step */
 #define JQC_VARIANT_CJR (1 << 11)      /* row-lane mode, lane = bra component i only, the j components in registers (small kets) */
+#define JQC_VARIANT_NKS(log2n) ((log2n) << 12) /* lane-per-quartet mode: 2 (log2n=1) or 4 (2) ket tile pairs staged and screened
+                                          per iteration, so classes with few candidates per tile pair still fill 256 lanes */
 
 const char* jqc_last_error(void);
 const char* jqc_version(void);

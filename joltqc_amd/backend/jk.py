@@ -57,6 +57,8 @@ def forced_variant(ang, v):
     the wave-local variant only where a quartet fits one wave."""
     if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > TILE1Q_FORCE_MAX:
         return _lib.ALGO_TILE
+    if (v & 0xf) != _lib.ALGO_TILE1Q:
+        v &= ~0x3000                                  # several ket pairs per iteration: lane-per-quartet mode only
     nf = lambda l: (l + 1) * (l + 2) // 2
     if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or nf(ang[0]) * nf(ang[1]) > 64):
         v &= ~0x400
@@ -93,6 +95,11 @@ def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None
     try:
         return _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, algo, compile_only)
     except RuntimeError:
+        if algo & 0x3000:
+            # several ket pairs per iteration did not fit LDS for this build of the class (e.g. its long-range form with the
+            # larger Rys table): same kernel with fewer ket pairs per iteration
+            nks = (algo >> 12) & 3
+            return gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, (algo & ~0x3000) | ((nks - 1) << 12), compile_only)
         # a variant forced through JQC_JK_ALGO=v<code> may not exist for every class (LDS budget): plain row-lane kernel
         if os.environ.get("JQC_JK_ALGO", "").lower().startswith("v") and (algo & 0xf) != _lib.ALGO_1Q1T:
             return _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, _lib.ALGO_TILE, compile_only)

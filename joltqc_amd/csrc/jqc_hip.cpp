@@ -354,6 +354,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     const int algo = algo_variant & 0xf;
     const int v_minw = (algo_variant >> 4) & 0xf;
     const int v_rys_l2 = (algo_variant >> 8) & 1, v_st1 = (algo_variant >> 9) & 1, v_wsync = (algo_variant >> 10) & 1, v_cjr = (algo_variant >> 11) & 1;
+    const int v_nks = (algo_variant >> 12) & 3;
     if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
     if (!do_j && !do_k) return fail(-1, "need do_j or do_k");
@@ -383,6 +384,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
         if (v_st1) d.push_back("-DST_LDS_MAX=0");
         if (v_wsync) d.push_back("-DWSYNC=1");
         if (v_cjr) d.push_back("-DCJR=1");
+        if (v_nks) d.push_back("-DNKS=" + std::to_string(1 << v_nks));
         if (tiled) {
             // Builds that spill vector registers to scratch also re-read the staging pointers from the kernarg segment
             // (KARG_RELOAD in jk_tile.hip: ~45 fewer SGPRs spilled to VGPR lanes); builds without scratch keep the

@@ -77,6 +77,9 @@ constexpr int G = WSYNC ? NWAVE * GW : TBLOCK / T;
 #ifndef RYS_LDS_MAX
 #define RYS_LDS_MAX 28672   // stage the class's Chebyshev table in LDS when it is at most this many bytes (nroots <= 5 in f64)
 #endif
+#ifndef NKS
+#define NKS 1       // ket tile pairs staged per iteration (lane-per-quartet mode: 2 or 4 where a tile pair has few candidates)
+#endif
 #ifndef MINW
 #define MINW 2      // waves/SIMD the register allocator leaves room for.  Never 1: builds with more than 256 registers per lane
                     // (AGPR spill space) gave wrong results in a few classes (tools/verify_scheme.py)
@@ -121,6 +124,9 @@ constexpr bool RYS_IN_LDS = RYS_TAB * (int)sizeof(real) <= RYS_LDS_MAX;
 static_assert(T <= TBLOCK && G >= 1 && NQ <= 65535, "tile geometry");
 static_assert((TSI + TSJ) * BASIS_STRIDE <= TBLOCK && (TSK + TSL) * BASIS_STRIDE <= TBLOCK, "shell rows of a tile pair are staged by one pass");
 static_assert(TBLOCK == 256 || !TILE_1Q, "the lane-per-quartet mode uses 256 threads");
+constexpr int KS_SHIFT = NKS == 1 ? 16 : NKS == 2 ? 15 : NKS == 4 ? 14 : 13;     // queue entry = candidate id | ket slot << KS_SHIFT
+static_assert(NKS == 1 || (TILE_1Q && (NKS == 2 || NKS == 4 || NKS == 8) && NQ <= (1 << KS_SHIFT)),
+              "several ket pairs per iteration: lane-per-quartet mode, 16-bit queue entries");
 
 // Rys root `r` only (same tables and branches as rys_roots in jk_common.h)
 __device__ __forceinline__ void rys_root_one(real x, real theta, real omega, const int r, const real* cheb,
@@ -251,16 +257,18 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         const unsigned* __restrict__ tpair_ao, const unsigned* __restrict__ tpair_pp, const real* __restrict__ pair_tab)
 {
     __shared__ unsigned s_nact[2];              // survivors of the current tile pair (double-buffered by iteration parity)
-    __shared__ unsigned short s_act[NQ];        // their candidate ids, appended wave by wave
-    __shared__ real sDij[WJ * WI], sDkl[WL * WK], sDik[WI * WK], sDil[WI * WL], sDjk[WJ * WK], sDjl[WJ * WL];
-    __shared__ double sJij[WJ * WI], sJkl[WL * WK], sKik[WI * WK], sKil[WI * WL], sKjk[WJ * WK], sKjl[WJ * WL];
+    // NKS ket tile pairs are staged and screened per iteration (lane-per-quartet mode only): classes with few candidates
+    // per tile pair fill the 256 lanes from several ket pairs; queue entry = candidate id | ket slot << KS_SHIFT
+    __shared__ unsigned short s_act[NKS * NQ];  // their candidate ids, appended wave by wave
+    __shared__ real sDij[WJ * WI], sDkl[NKS * WL * WK], sDik[NKS * WI * WK], sDil[NKS * WI * WL], sDjk[NKS * WJ * WK], sDjl[NKS * WJ * WL];
+    __shared__ double sJij[WJ * WI], sJkl[NKS * WL * WK], sKik[NKS * WI * WK], sKil[NKS * WI * WL], sKjk[NKS * WJ * WK], sKjl[NKS * WJ * WL];
 #if !TILE_1Q
     __shared__ real sT[NBUF * G * NROOTS * 3 * NT2];
 #endif
     // shell rows of the four tiles and per-primitive-pair prefactors {c_a c_b K_ab, 1/(a+b), a+b}:
     // every exp / reciprocal of the pair prefactors is evaluated once per tile pair, not once per quartet
-    __shared__ real sBas[(TSI + TSJ + TSK + TSL) * BASIS_STRIDE];
-    __shared__ real sPB[TSI * TSJ * 9 * 3], sPK[TSK * TSL * 9 * 3];
+    __shared__ real sBas[(TSI + TSJ + NKS * (TSK + TSL)) * BASIS_STRIDE];
+    __shared__ real sPB[TSI * TSJ * 9 * 3], sPK[NKS * TSK * TSL * 9 * 3];
     // Rys Chebyshev table of the class: every lane reads 28 coefficients of ITS OWN x-interval per root, i.e. 64
     // different cache lines per wave instruction from global memory; from LDS the same gather costs a few cycles
     __shared__ real sRys[RYS_IN_LDS ? RYS_TAB : 1];
@@ -302,6 +310,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     const int ish0 = pij >> 16, jsh0 = pij & 0xffff;
     const int i0 = aoij >> 16, j0 = aoij & 0xffff;           // first AO of the two tiles
     constexpr int OFF_J = TSI * BASIS_STRIDE, OFF_K = (TSI + TSJ) * BASIS_STRIDE, OFF_L = (TSI + TSJ + TSK) * BASIS_STRIDE;
+    constexpr int KSTR = (TSK + TSL) * BASIS_STRIDE;          // ket slot stride in sBas
     constexpr int NRYS = RYS_IN_LDS ? (RYS_TAB + TBLOCK - 1) / TBLOCK : 1;
     // ---- bra side, once per workgroup: issue every load, then write LDS
     {
@@ -322,13 +331,13 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         }
 #if DO_J
         for (int n = tid; n < WJ * WI; n += TBLOCK) sJij[n] = 0;
-        for (int n = tid; n < WL * WK; n += TBLOCK) sJkl[n] = 0;
+        for (int n = tid; n < NKS * WL * WK; n += TBLOCK) sJkl[n] = 0;
 #endif
 #if DO_K
-        for (int n = tid; n < WI * WK; n += TBLOCK) sKik[n] = 0;
-        for (int n = tid; n < WI * WL; n += TBLOCK) sKil[n] = 0;
-        for (int n = tid; n < WJ * WK; n += TBLOCK) sKjk[n] = 0;
-        for (int n = tid; n < WJ * WL; n += TBLOCK) sKjl[n] = 0;
+        for (int n = tid; n < NKS * WI * WK; n += TBLOCK) sKik[n] = 0;
+        for (int n = tid; n < NKS * WI * WL; n += TBLOCK) sKil[n] = 0;
+        for (int n = tid; n < NKS * WJ * WK; n += TBLOCK) sKjk[n] = 0;
+        for (int n = tid; n < NKS * WJ * WL; n += TBLOCK) sKjl[n] = 0;
 #endif
         if (tid < 2) s_nact[tid] = 0;
         if (tid < (TSI + TSJ) * BASIS_STRIDE) sBas[tid] = rb;
@@ -385,7 +394,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         }
         STAMP(2);
 #endif
-        for (int kt = kt0; kt < kt1; kt++) {
+        for (int kt = kt0; kt < kt1; kt += NKS) {
 #if KARG_RELOAD
             const KArgs AS4* ka = kargs();
             const int nao = ka->nao, nbas = ka->nbas;
@@ -400,17 +409,28 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             const real* __restrict__ pair_tab = ka->pair_tab;
             const real* __restrict__ D = ka->dm + idm * ((size_t)nao * nao);
 #endif
-            const unsigned pkl = tpair_sh[kl0 + kt], aokl = tpair_ao[kl0 + kt];
             if (qij + tpair_q[kl0 + kt] <= cut_lo) break;
-            const int ksh0 = pkl >> 16, lsh0 = pkl & 0xffff;
-            const int k0 = aokl >> 16, l0 = aokl & 0xffff;
+            int ksh0s[NKS], lsh0s[NKS], k0s[NKS], l0s[NKS];
+            bool kval[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                // (the ket list is sorted by its bound: once a pair fails the cut every later one does)
+                kval[ks] = ks == 0 || (kt + ks < kt1 && qij + tpair_q[kl0 + kt + ks] > cut_lo);
+                const unsigned pkl = kval[ks] ? tpair_sh[kl0 + kt + ks] : 0u, aokl = kval[ks] ? tpair_ao[kl0 + kt + ks] : 0u;
+                ksh0s[ks] = pkl >> 16; lsh0s[ks] = pkl & 0xffff;
+                k0s[ks] = aokl >> 16; l0s[ks] = aokl & 0xffff;
+            }
             parity ^= 1;
             // index arithmetic of the staging / flush loops is re-derived from an opaque copy of the thread id: keeps
             // the (cheap) loop-invariant addresses from being hoisted over the compute phase and spilled there
             int tid_s = tid;
             asm volatile("" : "+v"(tid_s));
 #define tid tid_s
-            {
+            if (tid == 0) s_nact[parity ^ 1] = 0;          // next iteration's counter (last read before this point)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                if (!kval[ks]) continue;
+                const int ksh0 = ksh0s[ks], lsh0 = lsh0s[ks], k0 = k0s[ks], l0 = l0s[ks];
                 // ---- issue: ket shell rows, primitive-pair inputs, five density sub-blocks
                 real rb = 0;
                 if (tid < (TSK + TSL) * BASIS_STRIDE) {
@@ -419,7 +439,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
                 constexpr int NPK = (TSK * TSL * 27 + TBLOCK - 1) / TBLOCK;
                 real rpk[NPK];
-                const real* __restrict__ ppk = pair_tab + (size_t)tpair_pp[kl0 + kt] * 27;
+                const real* __restrict__ ppk = pair_tab + (size_t)tpair_pp[kl0 + kt + ks] * 27;
 #pragma unroll
                 for (int u = 0; u < NPK; u++) rpk[u] = tid + u * TBLOCK < TSK * TSL * 27 ? ppk[tid + u * TBLOCK] : real(0);
 #if DO_J
@@ -439,7 +459,6 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 STAMP(3);
                 // ---- per-quartet screening of the NQ candidates of the tile pair (wave64 ballots); every wave appends
                 //      its survivors to the queue through one LDS counter
-                if (tid == 0) s_nact[parity ^ 1] = 0;          // next iteration's counter (last read before this point)
 #pragma unroll 2
                 for (int cand0 = cand_lo; cand0 < cand_hi; cand0 += TBLOCK) {
                     const int cd = cand0 + tid;
@@ -470,25 +489,26 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         unsigned base = 0;
                         if (lane == 0) base = atomicAdd(&s_nact[parity], (unsigned)__popcll(m));
                         base = __builtin_amdgcn_readfirstlane(base);
-                        if (keep) s_act[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)cd;
+                        if (keep) s_act[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(cd | (ks << KS_SHIFT));
                     }
                 }
                 // ---- write LDS
-                if (tid < (TSK + TSL) * BASIS_STRIDE) sBas[OFF_K + tid] = rb;
+                if (tid < (TSK + TSL) * BASIS_STRIDE) sBas[OFF_K + ks * KSTR + tid] = rb;
 #pragma unroll
                 for (int u = 0; u < NPK; u++)
-                    if (tid + u * TBLOCK < TSK * TSL * 27) sPK[tid + u * TBLOCK] = rpk[u];
+                    if (tid + u * TBLOCK < TSK * TSL * 27) sPK[ks * (TSK * TSL * 27) + tid + u * TBLOCK] = rpk[u];
 #if DO_J
-                tile_store(sDkl, rkl, tid);
+                tile_store(sDkl + ks * (WL * WK), rkl, tid);
 #endif
 #if DO_K
-                tile_store(sDik, rik, tid);
-                tile_store(sDil, ril, tid);
-                tile_store(sDjk, rjk, tid);
-                tile_store(sDjl, rjl, tid);
+                tile_store(sDik + ks * (WI * WK), rik, tid);
+                tile_store(sDil + ks * (WI * WL), ril, tid);
+                tile_store(sDjk + ks * (WJ * WK), rjk, tid);
+                tile_store(sDjl + ks * (WJ * WL), rjl, tid);
 #endif
             }
 #undef tid
+            const int ksh0 = ksh0s[0], lsh0 = lsh0s[0], k0 = k0s[0], l0 = l0s[0];      // (row-lane mode: one ket pair)
             STAMP(4);
             __syncthreads();
             STAMP(5);
@@ -501,15 +521,20 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #if TILE_1Q
             // ---------------- one quartet per lane: everything in registers, then LDS Fock tiles
             for (int q1 = tid; q1 < nact; q1 += TBLOCK) {
-                const int qd = s_act[q1];
+                const int qe = s_act[q1];
+                const int ks = NKS > 1 ? qe >> KS_SHIFT : 0, qd = NKS > 1 ? qe & ((1 << KS_SHIFT) - 1) : qe;
                 const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
-                const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
+                int kshb = ksh0s[0], lshb = lsh0s[0];
+#pragma unroll
+                for (int u = 1; u < NKS; u++)
+                    if (ks == u) { kshb = ksh0s[u]; lshb = lsh0s[u]; }
+                const int ish = ish0 + a, jsh = jsh0 + b, ksh = kshb + c, lsh = lshb + d;
                 const real* bi = sBas + a * BASIS_STRIDE;
                 const real* bj = sBas + OFF_J + b * BASIS_STRIDE;
-                const real* bk = sBas + OFF_K + c * BASIS_STRIDE;
-                const real* bl = sBas + OFF_L + d * BASIS_STRIDE;
+                const real* bk = sBas + OFF_K + ks * KSTR + c * BASIS_STRIDE;
+                const real* bl = sBas + OFF_L + ks * KSTR + d * BASIS_STRIDE;
                 const real* pb = sPB + (a * TSJ + b) * 27;
-                const real* pk = sPK + (c * TSL + d) * 27;
+                const real* pk = sPK + (ks * TSK * TSL + c * TSL + d) * 27;
                 const real rix = bi[0], riy = bi[1], riz = bi[2];
                 const real rkx = bk[0], rky = bk[1], rkz = bk[2];
                 const real rij[3] = {bj[0] - rix, bj[1] - riy, bj[2] - riz};
@@ -570,13 +595,20 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     }
                 }
                 const int iA = a * NFI, jA = b * NFJ, kA = c * NFK, lA = d * NFL;
+                // ket-slot views of the ket-dependent tiles
+                const real* sDkl_q = sDkl + ks * (WL * WK); const real* sDik_q = sDik + ks * (WI * WK);
+                const real* sDil_q = sDil + ks * (WI * WL); const real* sDjk_q = sDjk + ks * (WJ * WK);
+                const real* sDjl_q = sDjl + ks * (WJ * WL);
+                double* sJkl_q = sJkl + ks * (WL * WK); double* sKik_q = sKik + ks * (WI * WK);
+                double* sKil_q = sKil + ks * (WI * WL); double* sKjk_q = sKjk + ks * (WJ * WK);
+                double* sKjl_q = sKjl + ks * (WJ * WL);
 #if DO_J
                 {
                     real jkl[NFK * NFL], dkl[NFK * NFL];
 #pragma unroll
                     for (int k = 0; k < NFK; k++)
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) { jkl[k * NFL + l] = 0; dkl[k * NFL + l] = sDkl[(lA + l) * WK + kA + k]; }
+                        for (int l = 0; l < NFL; l++) { jkl[k * NFL + l] = 0; dkl[k * NFL + l] = sDkl_q[(lA + l) * WK + kA + k]; }
 #pragma unroll
                     for (int i = 0; i < NFI; i++)
 #pragma unroll
@@ -594,7 +626,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma unroll
                     for (int k = 0; k < NFK; k++)
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) lds_add(&sJkl[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
+                        for (int l = 0; l < NFL; l++) lds_add(&sJkl_q[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
                 }
 #endif
 #if DO_K
@@ -603,17 +635,17 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma unroll
                     for (int j = 0; j < NFJ; j++) {
 #pragma unroll
-                        for (int k = 0; k < NFK; k++) { kjk[j * NFK + k] = 0; djk[j * NFK + k] = sDjk[(jA + j) * WK + kA + k]; }
+                        for (int k = 0; k < NFK; k++) { kjk[j * NFK + k] = 0; djk[j * NFK + k] = sDjk_q[(jA + j) * WK + kA + k]; }
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) { kjl[j * NFL + l] = 0; djl[j * NFL + l] = sDjl[(jA + j) * WL + lA + l]; }
+                        for (int l = 0; l < NFL; l++) { kjl[j * NFL + l] = 0; djl[j * NFL + l] = sDjl_q[(jA + j) * WL + lA + l]; }
                     }
 #pragma unroll
                     for (int i = 0; i < NFI; i++) {
                         real kik[NFK], kil[NFL], dik[NFK], dil[NFL];
 #pragma unroll
-                        for (int k = 0; k < NFK; k++) { kik[k] = 0; dik[k] = sDik[(iA + i) * WK + kA + k]; }
+                        for (int k = 0; k < NFK; k++) { kik[k] = 0; dik[k] = sDik_q[(iA + i) * WK + kA + k]; }
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) { kil[l] = 0; dil[l] = sDil[(iA + i) * WL + lA + l]; }
+                        for (int l = 0; l < NFL; l++) { kil[l] = 0; dil[l] = sDil_q[(iA + i) * WL + lA + l]; }
 #pragma unroll
                         for (int j = 0; j < NFJ; j++)
 #pragma unroll
@@ -627,16 +659,16 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                     kjl[j * NFL + l] += v * dik[k];
                                 }
 #pragma unroll
-                        for (int k = 0; k < NFK; k++) lds_add(&sKik[(iA + i) * WK + kA + k], (double)kik[k]);
+                        for (int k = 0; k < NFK; k++) lds_add(&sKik_q[(iA + i) * WK + kA + k], (double)kik[k]);
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) lds_add(&sKil[(iA + i) * WL + lA + l], (double)kil[l]);
+                        for (int l = 0; l < NFL; l++) lds_add(&sKil_q[(iA + i) * WL + lA + l], (double)kil[l]);
                     }
 #pragma unroll
                     for (int j = 0; j < NFJ; j++) {
 #pragma unroll
-                        for (int k = 0; k < NFK; k++) lds_add(&sKjk[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
+                        for (int k = 0; k < NFK; k++) lds_add(&sKjk_q[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) lds_add(&sKjl[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
+                        for (int l = 0; l < NFL; l++) lds_add(&sKjl_q[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
                     }
                 }
 #endif
@@ -1066,18 +1098,21 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             double* __restrict__ vj = kf->vj;
             double* __restrict__ vk = kf->vk;
 #endif
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                if (!kval[ks]) continue;
+                const int k0 = k0s[ks], l0 = l0s[ks];
 #if DO_J
-            flush_tile(sJkl, vj + idm * nao2, nao, l0, k0, WL, WK, tid);
+                flush_tile(sJkl + ks * (WL * WK), vj + idm * nao2, nao, l0, k0, WL, WK, tid);
 #endif
 #if DO_K
-            {
                 double* __restrict__ K = vk + idm * nao2;
-                flush_tile(sKik, K, nao, i0, k0, WI, WK, tid);
-                flush_tile(sKil, K, nao, i0, l0, WI, WL, tid);
-                flush_tile(sKjk, K, nao, j0, k0, WJ, WK, tid);
-                flush_tile(sKjl, K, nao, j0, l0, WJ, WL, tid);
-            }
+                flush_tile(sKik + ks * (WI * WK), K, nao, i0, k0, WI, WK, tid);
+                flush_tile(sKil + ks * (WI * WL), K, nao, i0, l0, WI, WL, tid);
+                flush_tile(sKjk + ks * (WJ * WK), K, nao, j0, k0, WJ, WK, tid);
+                flush_tile(sKjl + ks * (WJ * WL), K, nao, j0, l0, WJ, WL, tid);
 #endif
+            }
             }
 #undef tid
             STAMP(8);

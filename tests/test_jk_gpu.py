@@ -172,10 +172,11 @@ def test_ket_chunks_and_workgroup_splits(monkeypatch):
 
 
 @pytest.mark.parametrize("variant", [0x21, 0x21 | 0x100, 0x21 | 0x400, 0x21 | 0x100 | 0x400, 0x22, 0x32, 0x21 | 0x800,
-                                     0x21 | 0x100 | 0x800])
+                                     0x21 | 0x100 | 0x800, 0x1022, 0x2022, 0x3022])
 def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
     """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
-    L2 | single TRR buffer | wave-local steps; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.
+    L2 | single TRR buffer | wave-local steps | j in registers | 2, 4, 8 ket pairs per iteration; include/jqc_hip.h
+    JQC_VARIANT_*): each must give the same J and K.
     Role of the reference's 1q1t == 1qnt cross-check (jqc/backend/data/generate_fragment.py:278-309)."""
     from joltqc_amd.backend import jk as router
     from oracle import dense

@@ -16,7 +16,9 @@ os.environ["JQC_KERNEL_CACHE"] = CACHE
 
 MINW = lambda n: n << 4
 RYS_L2, ST1, WSYNC, CJR = 1 << 8, 1 << 9, 1 << 10, 1 << 11
+NKS = lambda log2n: log2n << 12
 CANDIDATES = [2 | MINW(1), 2 | MINW(2), 2 | MINW(3),
+              2 | MINW(2) | NKS(1), 2 | MINW(2) | NKS(2), 2 | MINW(2) | NKS(3), 2 | MINW(3) | NKS(1),
               1 | MINW(1), 1 | MINW(2), 1 | MINW(1) | RYS_L2, 1 | MINW(2) | RYS_L2, 1 | MINW(2) | RYS_L2 | ST1,
               1 | MINW(3) | RYS_L2 | ST1,
               1 | MINW(1) | WSYNC, 1 | MINW(2) | WSYNC, 1 | MINW(1) | RYS_L2 | WSYNC, 1 | MINW(2) | RYS_L2 | WSYNC,
@@ -114,6 +116,10 @@ def allowed(v):
     the same source being correct at two waves per SIMD; the measured cost of the exclusion is 2.5 %
     (profiles/r01_autotune_last_run.json).  The lane-per-quartet kernels at three waves per SIMD pass every gate."""
     minw = (v >> 4) & 0xf
+    if (v & 0xf) == 2:
+        # lane-per-quartet kernels: no build of this mode has failed a gate, including the 512-register ones the compiler
+        # produces by itself when several ket pairs per iteration (NKS) push LDS past two workgroups per CU
+        return minw != 1
     return minw != 1 and not ((v & 0xf) == 1 and minw == 3)
 
 
