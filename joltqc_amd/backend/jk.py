@@ -65,10 +65,15 @@ def forced_variant(ang, v):
     return v
 
 
-def select_algo(ang, fp32=False):
+def select_algo(ang, fp32=False, small=False):
     """Algorithm + tuning variant of class ``ang`` (low 4 bits: lib.ALGO_*, bits 4-7: waves per SIMD, bit 8: Rys table
-    through L2, bit 9: single TRR buffer; include/jqc_hip.h JQC_VARIANT_*)."""
+    through L2, bit 9: single TRR buffer, ...; include/jqc_hip.h JQC_VARIANT_*).  ``small``: the launch has fewer
+    workgroups than the chunking target (a benzene-size molecule): the "fp64_small" table, tuned on benzene, overrides
+    the main one, which is tuned on a 112-atom molecule (one-workgroup-per-CU builds lose when the grid cannot fill
+    the chip anyway)."""
     t = _table().get("fp32" if fp32 else "fp64", {})
+    if small and not fp32:
+        t = {**t, **_table().get("fp64_small", {})}
     forced = os.environ.get("JQC_JK_ALGO")
     if forced:
         f = forced.lower()

@@ -522,7 +522,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     sid = side[n % len(side)]
                     sp = sid.cuda_stream
                     h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False,
-                                                algo=_router.select_algo(ang))
+                                                algo=_router.select_algo(ang, small=nblk < TARGET_WGS))
                     probing = state["probe"] is not None and (state["probe"] == "all" or tuple(state["probe"]) == tuple(ang))
                     if probing:
                         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
