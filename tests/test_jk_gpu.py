@@ -98,6 +98,23 @@ def test_jk_fp32_and_mixed_precision():
     assert np.abs(_np(vj) - rj).max() < 1e-7 and np.abs(_np(vk) - rk).max() < 1e-7
 
 
+def test_mixed_precision_with_the_fp32_window_split_off(monkeypatch):
+    """The reference's mixed mode proper (jk.py:330-420): estimate in (cutoff_fp32, cutoff_fp64] -> fp32 kernel, above -> fp64
+    kernel.  The gfx950 scheme table leaves the window with the fp64 kernel (measured faster); JQC_FP32_WINDOW=1 forces the
+    split for every class, which this test keeps correct."""
+    from oracle import dense
+    monkeypatch.setenv("JQC_FP32_WINDOW", "1")
+    # (a water molecule has no quartet below 1e-7: the window is widened to 1e-4 so that both kernels get work)
+    mol, lay, jkmix = _setup(H2O, "def2-svp", cut64=1e-4, cut32=1e-13)
+    dm = _dm(mol.nao)
+    rj, rk = dense.get_jk(lay, dm, hermi=1)
+    vj, vk = jkmix(mol, dm, hermi=1)
+    n64, n32, _ = jkmix.quartet_counts()
+    assert n64 > 0 and n32 > 0
+    assert n64 + n32 <= len(dense.canonical_quartets(lay))
+    assert np.abs(_np(vj) - rj).max() < 1e-7 and np.abs(_np(vk) - rk).max() < 1e-7
+
+
 def test_jk_screening_far_apart_atoms():
     # reference test_jk.py:250-276: 100 Bohr apart -> inter-atomic quartets are screened out
     from oracle import dense
