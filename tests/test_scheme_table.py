@@ -1,0 +1,91 @@
+"""Host logic around the gfx950 scheme table (joltqc_amd/data/gfx950_scheme.json, role of the reference's
+jqc/backend/data/optimal_scheme_<GPU>_fp64.json + backend/jk.py:37-53): table shape, the small-launch override, what the
+tuner may pick, and the generator's degrade path for variants that do not fit LDS.  No GPU needed (compile-only)."""
+import glob
+import json
+import os
+import subprocess
+
+import pytest
+
+from joltqc_amd.backend import jk as router
+from joltqc_amd.backend import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _classes(lmax):
+    return [(a, b, c, d) for a in range(lmax + 1) for b in range(a + 1) for c in range(a + 1) for d in range(c + 1)]
+
+
+def test_every_class_up_to_g_has_an_entry_and_obeys_the_build_rules():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import autotune
+    with open(os.path.join(ROOT, "joltqc_amd", "data", "gfx950_scheme.json")) as f:
+        sch = json.load(f)
+    for prec in ("fp64", "fp32"):
+        for ang in _classes(4):
+            v = sch[prec].get(router.class_key(ang))
+            assert v is not None, (prec, ang)
+            assert (v & 0xf) in (L.ALGO_TILE, L.ALGO_TILE1Q), (prec, ang, hex(v))
+            assert autotune.allowed(v), (prec, ang, hex(v))         # no banned register allocation in the table
+            if (v & 0xf) == L.ALGO_TILE1Q:
+                assert router.nint(ang) <= router.TILE1Q_FORCE_MAX
+            else:
+                assert not (v & 0x3000)                              # several ket pairs: lane-per-quartet mode only
+    for key, v in sch["fp64_small"].items():
+        assert autotune.allowed(v) and key in sch["fp64"]
+
+
+def test_small_launches_use_the_override_table(monkeypatch):
+    monkeypatch.delenv("JQC_JK_ALGO", raising=False)
+    with open(os.path.join(ROOT, "joltqc_amd", "data", "gfx950_scheme.json")) as f:
+        sch = json.load(f)
+    changed = 0
+    for ang in _classes(3):
+        key = router.class_key(ang)
+        big, small = router.select_algo(ang), router.select_algo(ang, small=True)
+        assert big == sch["fp64"][key]
+        assert small == sch["fp64_small"].get(key, big)
+        changed += big != small
+        assert router.select_algo(ang, True, small=True) == sch["fp32"][key]      # fp32 has one table
+    assert changed == len(sch["fp64_small"]) > 0
+
+
+def test_forced_variant_respects_what_a_class_supports():
+    assert router.forced_variant((3, 3, 3, 3), 0x2022) == L.ALGO_TILE          # integral block too large for one lane
+    assert router.forced_variant((2, 1, 1, 0), 0x2022) == 0x2022
+    assert router.forced_variant((2, 1, 1, 0), 0x1021) == 0x21                # row lanes: one ket pair per iteration
+    assert router.forced_variant((2, 1, 1, 0), 0x421) & 0x400                 # 18 row lanes fit one wave
+    assert not router.forced_variant((3, 3, 1, 0), 0x421) & 0x400             # 100 row lanes do not
+
+
+def test_too_many_ket_pairs_degrade_to_fewer(tmp_path, monkeypatch):
+    """(dp|ps) with 8 ket pairs per iteration needs > 160 KB of LDS: the router retries with 4 (still the HIP path)."""
+    with pytest.raises(RuntimeError):
+        L.gen_jk_kernel((2, 1, 1, 0), True, True, False, False, 0x3022, compile_only=True)
+    router.gen_jk_kernel.cache_clear()
+    h = router.gen_jk_kernel((2, 1, 1, 0), True, True, False, False, 0x3022, True)
+    assert h >= 0
+    router.gen_jk_kernel.cache_clear()
+
+
+def test_builds_with_scratch_reread_their_arguments():
+    """Generator policy (jqc_hip.cpp:jqc_gen_jk_kernel): a class kernel whose code object spills VGPRs to scratch is the
+    KARG_RELOAD build, which keeps (almost) no SGPR spilled; tools/spill_survey.py reads the same metadata."""
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not found")
+    import re
+    L.gen_jk_kernel((2, 1, 1, 0), True, True, False, False, 0x22, compile_only=True)      # scratch build
+    L.gen_jk_kernel((1, 0, 1, 0), True, True, False, False, 0x22, compile_only=True)      # no scratch
+    def meta(pattern):
+        f = sorted(glob.glob(os.path.join(L.KERNEL_CACHE, pattern)), key=os.path.getmtime)[-1]
+        out = subprocess.run([readelf, "--notes", f], capture_output=True, text=True).stdout
+        g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, out).group(1))
+        return g("private_segment_fixed_size"), g("sgpr_spill_count")
+    scratch, sgpr_spills = meta("jk34_2110_j1k1_lr0_f64_*.hsaco")
+    assert scratch > 0 and sgpr_spills <= 8
+    scratch, sgpr_spills = meta("jk34_1010_j1k1_lr0_f64_*.hsaco")
+    assert scratch == 0
