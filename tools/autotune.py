@@ -3,7 +3,8 @@ jqc/backend/data/generate_fragment.py + optimal_scheme_<GPU>_fp64.json).
 
   build   (CPU, here)  : compile every candidate variant of every class into joltqc_amd/csrc/kcache_tune
   run     (GPU box)    : time every class under every variant on a workload -> gpurun_out/autotune_<workload>.json
-  merge   (CPU)        : best variant per class -> joltqc_amd/data/gfx950_scheme.json
+  merge   (CPU)        : best variant per class -> joltqc_amd/data/gfx950_scheme.json ("fp64" table, or "fp32" with JQC_TUNE_FP32=1)
+  merge-small (CPU)    : classes whose best variant on a benzene-size workload differs -> the "fp64_small" override table
 
 usage: python tools/autotune.py build | run [workload] | merge <json> [<json2> ...]
 """
@@ -141,7 +142,7 @@ def merge(files):
         for key, (v, ms) in per.items():
             best.setdefault(key, v)
     old = json.load(open(path))
-    for prec in ("fp64", "fp32"):
+    for prec in (("fp32",) if FP32 else ("fp64",)):          # JQC_TUNE_FP32=1: the files are fp32 timings
         for ang in classes(4):
             key = str(1000 * ang[0] + 100 * ang[1] + 10 * ang[2] + ang[3])
             k4 = "%d%d%d%d" % ang
