@@ -28,7 +28,7 @@ def fp32_pays(ang):
     force = os.environ.get("JQC_FP32_WINDOW")
     if force is not None:
         return force == "1"
-    return bool(_table().get("fp32_pays", {}).get(class_key(ang), True))
+    return bool(_table().get("fp32_pays", {}).get(class_key(ang), False))    # unmeasured classes (g): one fp64 launch
 
 
 def class_cost_table():
