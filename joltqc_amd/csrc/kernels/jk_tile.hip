@@ -9,13 +9,16 @@
 // is what the chip-wide atomic rate of MI355X demands (MI355X_MICROARCH.md "Global float atomics").
 //
 // Two compute modes (compile time):
-//  TILE_1Q=1  one quartet per lane, all integrals of the quartet in registers (small classes);
+//  TILE_1Q=1  one quartet per lane, all integrals of the quartet in registers (classes up to ~180 integrals).
+//             NKS = 2/4/8 stages and screens that many ket pairs per iteration, so the survivor queue fills the 256
+//             lanes where a tile pair has few candidates; with NKS >= 4 LDS allows one workgroup per CU and the
+//             compiler allocates up to 512 registers per lane (no scratch) -- the fastest form for the d/f classes;
 //  TILE_1Q=0  a quartet is evaluated by T = NFI*NFJ "row lanes" (one per bra Cartesian pair (ci,cj)),
 //             G = 256/T quartets in flight.  Per primitive combination
 //     phase A  G*3*NROOTS "job" lanes (packed into the first waves of the workgroup) compute one Rys
 //              root and run the transfer recurrence (TRR) of one (root, axis) into LDS
-//              t[root][axis][a<=LIJ][c<=LKL]; double-buffered, so phase A of the next primitive
-//              combination overlaps phase B of the current one and one barrier per combination remains;
+//              t[root][axis][a<=LIJ][c<=LKL] (the double-buffered schedule that overlapped phase A of the
+//              next combination with phase B is switched off: TRR_DOUBLE_BUFFER);
 //     phase B  every row lane contracts t with its own bra horizontal-recurrence weights, runs the ket
 //              horizontal recurrence in registers and accumulates its E = CW*NFL integrals
 //              (compile-time indices only: no scratch, no LDS traffic in the inner product loop).
