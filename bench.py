@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: J/K Fock-build wall-time and ERI quartets/s, def2-TZVPP (BASELINE.json).
 
-A "step" is ONE get_jk call (J and K, FP64, hermi=1, one density matrix) on benzene / def2-TZVPP
-(BASELINE.json configs[1]); the density matrix is synthetic (``rand; D = R R^T``, seed 9, the
-reference's own test convention, jqc/pyscf/tests/test_jk.py:68-71) and resident in HBM before the
-timed region.  With N > 1 ranks (torch.distributed, backend nccl = RCCL) the quartet work of the SAME
-molecule is dealt round-robin to the ranks and the raw Fock contributions are summed with one
-all-reduce per step (strong scaling).
+A "step" is ONE get_jk call (J and K, FP64, hermi=1, one density matrix).  Default workload: the 112-atom CHNO
+molecule ``0112-elongated-nitrogenous`` with def2-TZVPP -- the Taxol-size stand-in of the north-star target (Taxol
+C47H51NO14 has 113 atoms; the reference ships this geometry under benchmarks/molecules) -- ``--workload benzene`` gives
+BASELINE.json configs[1].  The density matrix is synthetic (``rand; D = R R^T``, seed 9, the reference's own test
+convention, jqc/pyscf/tests/test_jk.py:68-71: dense, i.e. no help from density screening) and resident in HBM before the
+timed region.
+
+``--gpus N``: when not already launched by torchrun (WORLD_SIZE unset) this process starts N ranks itself -- child
+processes, one per GPU, before anything here touches a GPU -- and rank 0 prints the line.  With N > 1 ranks
+(torch.distributed, backend nccl = RCCL) the quartet work of the SAME molecule is dealt to the ranks (cost-aware
+class/strip split) and the raw Fock contributions are summed with one all-reduce per step (strong scaling).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      FP64-VALU roofline of the dominant class kernel (the path is FMA-bound, not HBM- or
-                MFMA-bound: SURVEY.md 8d); achieved = algorithmic FLOP of that class per launch /
-                HIP-event duration of its launch, measured live in the timed region.
-  cpu_baseline  the CPU oracle (a scalar C port of the reference arithmetic) timed on a bounded random
-                sample of the same workload's canonical quartets, 1 core.
+  roofline      FP64-VALU roofline (the path is FMA-bound, not HBM- or MFMA-bound: SURVEY.md 8d) of the class kernel that
+                takes the most TIME (HIP events around every class launch, launches serialised on one stream for that leg);
+                achieved = algorithmic FLOP of that class per launch / its event duration; ``whole_path`` = all classes'
+                algorithmic FLOP / step wall-time.  ``traffic`` = HBM bytes per launch of that kernel from the committed
+                PMC summary (profiles/*pmc_traffic*.json, separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the
+                guide prescribes) with the algorithmic bytes beside it; null when no summary covers the kernel.
+  cpu_baseline  the CPU oracle (C restatement of the reference arithmetic, OpenMP over os.cpu_count() host cores) on a
+                bounded sample drawn from the dispatched class histogram of this workload; PySCF's get_jk is used
+                instead when it is importable on the box (it is not in this image).
+  grid_path     rho / vxc (GGA) of the DFT grid path on the same molecule and basis with a synthetic atom-centred grid:
+                grid points x AO pairs per second and the fraction of the FP64 MFMA peak (N = 1 only).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +39,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+DEFAULT_WORKLOAD = "0112-elongated-nitrogenous"
 
 
 def benzene_atoms():
@@ -48,50 +63,158 @@ def load_workload(name):
                   [2, [0.8, 1.0]], [3, [0.9, 1.0]], [4, [1.0, 1.0]]]
         return mole.Mole(atom=benzene_atoms(), basis={"C": shells, "H": shells}), "benzene, artificial s/p/d/f/g basis"
     path = os.path.join(ROOT, "joltqc_amd", "data", "molecules", name + ".xyz")
-    return mole.Mole(atom=mole.read_xyz(path), basis="def2-tzvpp"), f"{name} def2-TZVPP J+K"
+    atoms = mole.read_xyz(path)
+    el = [ln.split()[0] for ln in atoms.splitlines() if ln.strip()]
+    formula = "".join(f"{e}{el.count(e)}" for e in sorted(set(el), key=lambda e: (e != "C", e != "H", e)))
+    return mole.Mole(atom=atoms, basis="def2-tzvpp"), f"{name} ({formula}, {len(el)} atoms) RHF/def2-TZVPP J+K"
 
 
-def cpu_baseline(layout, seconds=12.0):
-    """Oracle (scalar C port) on a bounded random sample of canonical quartets of the same layout."""
-    from oracle import jk as O
-    rng = np.random.default_rng(0)
-    real = np.nonzero(~layout.pad_id)[0]
+def sample_quartets(layout, per_class, n, rng):
+    """``n`` canonical quartets drawn from the dispatched histogram {(ang, nprim pattern): count}: the class and the
+    primitive pattern follow the histogram, the shells inside the four (l, nprim) groups are uniform."""
+    groups = {}
+    for s in np.nonzero(~layout.pad_id)[0]:
+        groups.setdefault((int(layout.angs[s]), int(layout.nprims[s])), []).append(int(s))
+    groups = {k: np.array(v) for k, v in groups.items()}
+    keys = [k for k in per_class if k[1] is not None and sum(per_class[k]) > 0]
+    w = np.array([float(sum(per_class[k])) for k in keys])
+    counts = rng.multinomial(n, w / w.sum())
     nb = layout.nbasis
-    n = 8000000
-    i = rng.choice(real, n); j = rng.choice(real, n); k = rng.choice(real, n); l = rng.choice(real, n)
-    i, j = np.maximum(i, j), np.minimum(i, j)
-    k, l = np.maximum(k, l), np.minimum(k, l)
-    sw = i * nb + j < k * nb + l
-    i2, j2, k2, l2 = np.where(sw, k, i), np.where(sw, l, j), np.where(sw, i, k), np.where(sw, j, l)
-    q = np.stack([i2, j2, k2, l2], 1).astype(np.uint16)
+    out = []
+    for (ang, npr), c in zip(keys, counts):
+        if c == 0:
+            continue
+        i, j, k, l = (rng.choice(groups[(ang[x], npr[x])], c) for x in range(4))
+        i, j = np.maximum(i, j), np.minimum(i, j)
+        k, l = np.maximum(k, l), np.minimum(k, l)
+        sw = i * nb + j < k * nb + l
+        out.append(np.stack([np.where(sw, k, i), np.where(sw, l, j), np.where(sw, i, k), np.where(sw, j, l)], 1))
+    q = np.concatenate(out).astype(np.uint16)
+    return q[rng.permutation(len(q))]
+
+
+def cpu_baseline(mol, layout, per_class, seconds=15.0):
+    cores = os.cpu_count() or 1
+    try:                                           # the reference's own CPU oracle, when the box has it
+        from pyscf import gto as pgto, lib as plib, scf as pscf       # noqa: F401
+        have_pyscf = True
+    except ImportError:
+        have_pyscf = False
+    rng = np.random.default_rng(0)
+    if have_pyscf and hasattr(mol, "to_pyscf"):
+        pm = mol.to_pyscf()
+        plib.num_threads(cores)
+        dm = rng.random((pm.nao, pm.nao)); dm = dm @ dm.T
+        t0 = time.perf_counter()
+        pscf.hf.get_jk(pm, dm, hermi=1)
+        dt = time.perf_counter() - t0
+        return {"value": dt, "unit": "s per J/K build (pyscf.scf.hf.get_jk)", "cores": cores, "kind": "reference",
+                "sample": "the whole workload, one call"}
+    from oracle import jk as O
     dm = rng.random((layout.nao, layout.nao))
     dm = dm + dm.T
-    O.jk_raw(layout.packed, dm, q[:2000])          # warm-up / library load
+    O.jk_raw(layout.packed, dm, sample_quartets(layout, per_class, 2000, rng), nthreads=cores)          # warm-up / library load
+    batch = 20000 * cores
     done, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds and done < n:
-        m = min(200000, n - done)
-        O.jk_raw(layout.packed, dm, q[done:done + m])
-        done += m
+    while time.perf_counter() - t0 < seconds:
+        O.jk_raw(layout.packed, dm, sample_quartets(layout, per_class, batch, rng), nthreads=cores)
+        done += batch
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "quartets/s", "cores": 1, "kind": "port",
-            "sample": f"{done} uniformly random canonical quartets of the same shell table, oracle/jk_oracle.c, {dt:.1f} s"}
+    return {"value": done / dt, "unit": "quartets/s", "cores": cores, "kind": "port",
+            "sample": f"{done} canonical quartets drawn from this workload's dispatched (class, primitive pattern) histogram, "
+                      f"oracle/jk_oracle.c with OpenMP on {cores} threads, {dt:.1f} s (sampling included)"}
+
+
+def committed_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the newest committed PMC summary that lists it."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            rec = json.load(open(f)).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if rec:
+            return dict(rec, source=os.path.relpath(f, ROOT))
+    return None
+
+
+def grid_leg(mol, nsteps=3):
+    """rho / vxc (GGA) throughput on a synthetic atom-centred grid (the kernels do not care how a grid was generated)."""
+    import torch
+    from joltqc_amd.pyscf import rks
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from joltqc_amd.roofline import FP64_MFMA_PEAK_TFLOPS
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    rng = np.random.default_rng(0)
+    at = mol.atom_coords()
+    per = 3072
+    r = np.abs(rng.normal(0, 1.5, (mol.natm, per, 1))) + 0.05
+    u = rng.normal(size=(mol.natm, per, 3)); u /= np.linalg.norm(u, axis=-1, keepdims=True)
+    coords = (at[:, None, :] + r * u).reshape(-1, 3)
+    coords = coords[rks.arg_group_grids(coords)]
+    n = coords.shape[0] // 256 * 256
+
+    class G:
+        pass
+    g = G(); g.coords = coords[:n]; g.weights = np.full(n, 1e-3)
+    _, rho_k, vxc_k = rks.generate_rks_kernel(lay)
+    np.random.seed(9)
+    nocc = max(mol.nelectron // 2, 1)
+    c = np.random.rand(mol.nao, nocc) - 0.5
+    dm = torch.from_numpy(c @ c.T / nocc).cuda()
+    wv = torch.rand((4, n), dtype=torch.float64, device="cuda")
+    out = {"xc": "GGA", "ngrids": n, "nao": mol.nao, "grid": f"synthetic, {per} points per atom, box-sorted"}
+    for fn, arg, label in ((rho_k, dm, "rho"), (vxc_k, wv, "vxc")):
+        fn(mol, g, "GGA", arg); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(nsteps):
+            fn(mol, g, "GGA", arg)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / nsteps
+        m = rho_k.stats["nrow_h"].astype(float)                      # significant Cartesian AOs per 256-point block
+        pairs = float((m * m).sum()) * 256                            # grid points x AO pairs actually contracted
+        fl = 2.0 * pairs + 8.0 * 256 * float(m.sum())                # SURVEY 8d: 256 (2 m^2 + 8 m) per block
+        out[label] = {"ms": dt * 1e3, "points_x_ao_pairs_per_s": pairs / dt, "tflops": fl / dt / 1e12,
+                      "frac_fp64_mfma_peak": fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS, "mean_ao_per_block": float(m.mean())}
+    return out
+
+
+def spawn_ranks(args):
+    """Start ``--gpus`` ranks as child processes (this process has not touched a GPU) and relay rank 0's line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="benzene")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grid", action="store_true")
     args = ap.parse_args()
+    small = args.workload.startswith("benzene")
+    steps = args.steps if args.steps is not None else (20 if small else 5)
+    warmup = args.warmup if args.warmup is not None else (3 if small else 1)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
 
     import torch
     import torch.distributed as dist
     from joltqc_amd.constants import tile_width
     from joltqc_amd.pyscf import jk as jkmod
     from joltqc_amd.pyscf.basis import BasisLayout
-    from joltqc_amd.roofline import FP64_VALU_PEAK_TFLOPS, quartet_flops
+    from joltqc_amd.roofline import FP64_VALU_PEAK_TFLOPS, quartet_bytes, quartet_flops
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,20 +244,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         vj, vk = get_jk(mol, dm, hermi=1)
     torch.cuda.synchronize()
     n64, n32, per = get_jk.quartet_counts()
-    # dominant class = most algorithmic FLOP among this rank's classes
-    flops_by_ang = {}
+    flops_by_ang, bytes_by_ang, count_by_ang = {}, {}, {}
     for (ang, npr), (a, b) in per.items():
         flops_by_ang[ang] = flops_by_ang.get(ang, 0) + (a + b) * quartet_flops(ang, npr or (1, 1, 1, 1))
-    dom = max(flops_by_ang, key=flops_by_ang.get)
+        bytes_by_ang[ang] = bytes_by_ang.get(ang, 0) + (a + b) * quartet_bytes(ang)
+        count_by_ang[ang] = count_by_ang.get(ang, 0) + a + b
     total_flops = sum(flops_by_ang.values())
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         vj, vk = get_jk(mol, dm, hermi=1)
     barrier()
     dt = time.perf_counter() - t0
@@ -146,38 +269,66 @@ def main():
     dt = float(tmax.item())
     quartets, flops_all = float(nq[0].item()), float(nq[1].item())
 
-    # roofline leg: the dominant class kernel bracketed by HIP events on its own stream, class kernels
-    # launched back to back on ONE stream (in the timed region above they overlap on several streams,
-    # which makes a single kernel's duration ill-defined); same process, same inputs, right after the loop
+    # roofline leg: EVERY class kernel bracketed by HIP events on the stream it is launched on, class kernels launched
+    # back to back on ONE stream (in the timed region above they overlap on several streams, which makes a single
+    # kernel's duration ill-defined); same process, same inputs, right after the timed loop.  The kernel reported is
+    # the one that takes the most time on this rank.
     get_jk.set_streams(1)
-    get_jk.set_probe(dom)
-    for _ in range(max(3, min(args.steps, 10))):
+    get_jk.set_probe("all")
+    nprobe = 3 if small else 2
+    for _ in range(nprobe):
         get_jk(mol, dm, hermi=1)
     torch.cuda.synchronize()
-    evs = get_jk.stats.get("probe_events", [])
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else None
+    tm = {}
+    for ang, (e0, e1) in zip(get_jk.stats.get("probe_classes", []), get_jk.stats.get("probe_events", [])):
+        tm.setdefault(ang, []).append(e0.elapsed_time(e1))
+    tm = {a: float(np.mean(v)) for a, v in tm.items()}
+    serial_ms = sum(tm.values())
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        achieved = flops_by_ang[dom] / (kern_ms * 1e-3) / 1e12 if kern_ms else None
+        from joltqc_amd.backend import jk as router
+        ms = dt / steps * 1e3
+        dom = max(tm, key=tm.get)
+        kern_ms = tm[dom]
+        achieved = flops_by_ang.get(dom, 0) / (kern_ms * 1e-3) / 1e12
+        mode = router.select_algo(dom, small=False) & 0xf
+        kname = ("jk_tile1q_" if mode == 2 else "jk_tile512_" if mode == 3 else "jk_tile_") + "%d%d%d%d" % dom
+        best = max(tm, key=lambda a: flops_by_ang.get(a, 0) / tm[a])
         out = {
-            "metric": "ERI quartets/s (J/K Fock build, def2-TZVPP)", "value": quartets * args.steps / dt,
-            "unit": "quartets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "ERI quartets/s (J/K Fock build, def2-TZVPP)", "value": quartets * steps / dt,
+            "unit": "quartets/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": ms, "jk_wall_s": ms * 1e-3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wname, "nao": mol.nao, "split_shells": int((~layout.pad_id).sum()),
+            "config": {"workload": wname, "natm": mol.natm, "nao": mol.nao, "split_shells": int((~layout.pad_id).sum()),
                        "quartets_per_step": quartets, "model_gflop_per_step": flops_all / 1e9,
-                       "whole_path_tflops": flops_all * args.steps / dt / 1e12,
-                       "density": "rand(nao,nao) R R^T seed 9", "cutoff": 1e-13,
+                       "density": "rand(nao,nao) R R^T seed 9 (dense: no density screening)", "cutoff": 1e-13,
                        "parallelism": f"quartet work sharded over {world} rank(s) (cost-aware class/strip split) + 1 Fock all-reduce"},
-            "roofline": {"bound": "valu_fp64", "kernel": "jk_tile*_%d%d%d%d" % dom,
+            "roofline": {"bound": "valu_fp64", "kernel": kname, "selected_by": "largest measured launch time (HIP events, serial streams)",
                          "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VALU_PEAK_TFLOPS if achieved else None,
-                         "kernel_ms": kern_ms, "kernel_gflop": flops_by_ang[dom] / 1e9, "traffic": None},
+                         "frac": achieved / FP64_VALU_PEAK_TFLOPS,
+                         "kernel_ms": kern_ms, "kernel_gflop": flops_by_ang.get(dom, 0) / 1e9,
+                         "kernel_quartets": count_by_ang.get(dom, 0),
+                         "algorithmic_bytes": bytes_by_ang.get(dom, 0), "traffic": None,
+                         "whole_path": {"achieved": flops_all * steps / dt / 1e12,
+                                        "frac": flops_all * steps / dt / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                        "serial_kernel_sum_ms": serial_ms, "classes": len(tm)},
+                         "best_kernel": {"kernel": "%d%d%d%d" % best,
+                                         "achieved": flops_by_ang.get(best, 0) / tm[best] / 1e9,
+                                         "frac": flops_by_ang.get(best, 0) / tm[best] / 1e9 / FP64_VALU_PEAK_TFLOPS}},
         }
+        tr = committed_traffic(kname) if args.workload == DEFAULT_WORKLOAD else None
+        if tr:
+            out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+            out["roofline"]["traffic_detail"] = tr
+        if world == 1 and not args.no_grid:
+            try:
+                out["grid_path"] = grid_leg(mol)
+            except Exception as e:  # noqa: BLE001  (the headline must survive a failure of the extra leg)
+                out["grid_path"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(layout)
+            out["cpu_baseline"] = cpu_baseline(mol, layout, per)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -92,20 +92,75 @@ def select_algo(ang, fp32=False, small=False):
     return int(v)
 
 
+def _lds_overflow(err):
+    """hiprtc's message when a build does not fit the 160 KiB of LDS of a gfx950 CU."""
+    return "local memory" in str(err) and "exceeds limit" in str(err)
+
+
+def kernel_key(ang, do_j, do_k, rys_lr, fp32, algo):
+    """Name of one class-kernel BUILD (same string the library keys its code objects on, minus tile widths and source tag)."""
+    return "jk%d_%d%d%d%d_j%dk%d_lr%d_%s" % (int(algo), *ang, int(do_j), int(do_k), int(rys_lr), "f32" if fp32 else "f64")
+
+
+_MANIFEST = os.path.join(os.path.dirname(_SCHEME), "verified_kernels.json")
+
+
+@lru_cache(maxsize=1)
+def _manifest():
+    """Builds that passed the gates of the scheme table (tests/test_jk_gpu.py all-class / all-variant tests,
+    tests/test_jk_fullsize_gpu.py) for one version of the kernel sources and one compiler: written by
+    tools/make_manifest.py after a green GPU run.  A build that is not listed -- another variant forced through
+    JQC_JK_ALGO, JQC_EXTRA_DEFS, edited sources, another hiprtc -- is cross-checked against the independent
+    one-quartet-per-lane kernel on its first use (joltqc_amd/pyscf/jk.py)."""
+    if os.path.exists(_MANIFEST):
+        with open(_MANIFEST) as f:
+            return json.load(f)
+    return {}
+
+
+def is_verified(ang, do_j, do_k, rys_lr, fp32, algo):
+    if os.environ.get("JQC_TRUST_KERNELS") == "1":          # kernel development / tuning runs
+        return True
+    m = _manifest()
+    if m.get("src_tag") != _lib.lib().jqc_source_tag().decode():
+        return False
+    return kernel_key(ang, do_j, do_k, rys_lr, fp32, algo) in _manifest_keys()
+
+
+@lru_cache(maxsize=1)
+def _manifest_keys():
+    return frozenset(_manifest().get("keys", ()))
+
+
+_resolved = {}
+
+
+def resolved_algo(ang, do_j, do_k, rys_lr, fp32, algo):
+    """The variant ``gen_jk_kernel`` actually built for a request (differs when a several-ket-pairs build did not fit LDS)."""
+    return _resolved.get((tuple(ang), bool(do_j), bool(do_k), bool(rys_lr), bool(fp32), int(algo)), int(algo))
+
+
 @lru_cache(maxsize=None)
 def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None, compile_only=False):
     ang = tuple(int(x) for x in ang)
     if algo is None:
         algo = select_algo(ang, fp32)
-    try:
-        return _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, algo, compile_only)
-    except RuntimeError:
-        if algo & 0x3000:
-            # several ket pairs per iteration did not fit LDS for this build of the class (e.g. its long-range form with the
-            # larger Rys table): same kernel with fewer ket pairs per iteration
-            nks = (algo >> 12) & 3
-            return gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, (algo & ~0x3000) | ((nks - 1) << 12), compile_only)
-        # a variant forced through JQC_JK_ALGO=v<code> may not exist for every class (LDS budget): plain row-lane kernel
-        if os.environ.get("JQC_JK_ALGO", "").lower().startswith("v") and (algo & 0xf) != _lib.ALGO_1Q1T:
-            return _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, _lib.ALGO_TILE, compile_only)
-        raise
+    want = int(algo)
+    while True:
+        try:
+            h = _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, algo, compile_only)
+            _resolved[(ang, bool(do_j), bool(do_k), bool(rys_lr), bool(fp32), want)] = int(algo)
+            return h
+        except RuntimeError as e:
+            # the ONE expected failure: several ket pairs per iteration (or the j-in-registers form) do not fit LDS for this
+            # build of the class (e.g. its long-range form with the larger Rys table) -> same kernel with fewer ket
+            # pairs per iteration, then the plain row-lane kernel.  Anything else (compiler error, missing source) is raised.
+            if not _lds_overflow(e):
+                raise
+            if algo & 0x3000:
+                nks = (algo >> 12) & 3
+                algo = (algo & ~0x3000) | ((nks - 1) << 12)
+            elif (algo & 0xf) != _lib.ALGO_TILE or (algo & 0xc00):
+                algo = _lib.ALGO_TILE | (algo & 0x1f0)
+            else:
+                raise

@@ -12,8 +12,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-KERNEL_SRC = os.path.join(CSRC, "kernels")
-KERNEL_CACHE = os.environ.get("JQC_KERNEL_CACHE", os.path.join(CSRC, "kcache"))
+# JQC_KERNEL_SRC / JQC_KERNEL_CACHE: kernel development against a scratch copy of the sources (own code-object cache), so
+# that the verified AOT set of the shipped sources stays usable until a change is adopted
+KERNEL_SRC = os.environ.get("JQC_KERNEL_SRC", os.path.join(CSRC, "kernels"))
+KERNEL_CACHE = os.environ.get("JQC_KERNEL_CACHE", os.path.join(CSRC, "kcache" if "JQC_KERNEL_SRC" not in os.environ else "kcache_dev"))
 LIB_PATH = os.path.join(CSRC, "libjqc_hip.so")
 
 ALGO_1Q1T = 0

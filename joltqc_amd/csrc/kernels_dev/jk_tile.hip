@@ -1,0 +1,1180 @@
+// J/K kernel, tiled form for gfx950.  Entry point: jk_tile.
+//
+// One 256-thread workgroup owns ONE bra shell-tile pair and walks a chunk of consecutive ket shell-tile
+// pairs of the Schwarz-sorted ket list (task row = rectangle of the two lists).  Per (bra pair, ket pair)
+// up to TSI*TSJ*TSK*TSL shell quartets are evaluated; their six density sub-blocks and six Fock
+// sub-blocks live in LDS.  Bra-side data (shell rows, primitive-pair prefactors, D_ij, the Rys table and
+// the J_ij accumulator) is staged once per workgroup, ket-side data once per ket pair.  Global f64
+// atomics are issued once per tile element (coalesced rows) instead of once per quartet element, which
+// is what the chip-wide atomic rate of MI355X demands (MI355X_MICROARCH.md "Global float atomics").
+//
+// Two compute modes (compile time):
+//  TILE_1Q=1  one quartet per lane, all integrals of the quartet in registers (classes up to ~180 integrals).
+//             NKS = 2/4/8 stages and screens that many ket pairs per iteration, so the survivor queue fills the 256
+//             lanes where a tile pair has few candidates; with NKS >= 4 LDS allows one workgroup per CU and the
+//             compiler allocates up to 512 registers per lane (no scratch) -- the fastest form for the d/f classes;
+//  TILE_1Q=0  a quartet is evaluated by T = NFI*NFJ "row lanes" (one per bra Cartesian pair (ci,cj)),
+//             G = 256/T quartets in flight.  Per primitive combination
+//     phase A  G*3*NROOTS "job" lanes (packed into the first waves of the workgroup) compute one Rys
+//              root and run the transfer recurrence (TRR) of one (root, axis) into LDS
+//              t[root][axis][a<=LIJ][c<=LKL] (the double-buffered schedule that overlapped phase A of the
+//              next combination with phase B is switched off: TRR_DOUBLE_BUFFER);
+//     phase B  every row lane contracts t with its own bra horizontal-recurrence weights, runs the ket
+//              horizontal recurrence in registers and accumulates its E = CW*NFL integrals
+//              (compile-time indices only: no scratch, no LDS traffic in the inner product loop).
+//   The six contractions then go to the LDS Fock tiles; J_kl, K_jk, K_jl are first summed in registers
+//   across consecutive quartets that share the destination block.
+//
+// Mathematics (what is computed) follows the reference kernels
+//   /root/reference/jqc/backend/jk/1q1t.cu:86-94 (symmetry factors), :174-242 (primitive prefactors,
+//   seeds), :250-330 (TRR), :336-382 (HRR), :423-638 (six contractions and their destinations) and
+//   /root/reference/jqc/backend/jk/screen_jk_tasks.cu:202-261 (per-quartet screening predicate);
+// the decomposition above replaces the reference's jk/1qnt.cu design and is this build's own.
+#include "jk_common.h"
+#include "jk_axis.h"
+
+// shells per tile edge, by angular momentum (host side: joltqc_amd/constants.py tile_width; the library passes -DTSWn)
+#ifndef TSW0
+#define TSW0 8
+#endif
+#ifndef TSW1
+#define TSW1 4
+#endif
+#ifndef TSW2
+#define TSW2 4
+#endif
+#ifndef TSW3
+#define TSW3 2
+#endif
+#ifndef TSW4
+#define TSW4 1
+#endif
+constexpr int ts_of(int l) { return l == 0 ? TSW0 : l == 1 ? TSW1 : l == 2 ? TSW2 : l == 3 ? TSW3 : TSW4; }
+constexpr int TSI = ts_of(LI), TSJ = ts_of(LJ), TSK = ts_of(LK), TSL = ts_of(LL);
+constexpr int NQ = TSI * TSJ * TSK * TSL;
+#ifndef CJR
+#define CJR 0       // row-lane mode with the bra j components in REGISTERS: lane = bra component ci only (T = nf_i lanes per
+                    // quartet), each lane runs the bra HRR for every cj and holds nf_j times more integrals.  For classes with a
+                    // small ket block (few integrals per (ci,cj) lane) the LDS reads of phase B are shared by nf_j times more
+                    // products and K_ik / K_il / J_ij need no cross-lane sum at all.
+#endif
+constexpr int EJ = CJR ? NFJ : 1;                    // bra j components held per lane
+constexpr int T = CJR ? NFI : NFI * NFJ;
+#ifndef TBLOCK
+#define TBLOCK 256   // threads per workgroup (512: two waves per SIMD share one set of LDS tiles; row-lane mode only)
+#endif
+#ifndef WSYNC
+#define WSYNC 0     // row-lane mode, T <= 64: every quartet lives inside ONE wave (phase A by lanes of the same wave), so the
+                    // step loop needs no workgroup barrier and the waves of a workgroup drift apart (LDS atomics of one
+                    // overlap the arithmetic of another); costs the 64 % T lanes left over in every wave
+#endif
+constexpr int NWAVE = TBLOCK / 64;
+constexpr int GW = T <= 64 ? 64 / T : 0;          // quartets per wave (WSYNC)
+constexpr int G = WSYNC ? NWAVE * GW : TBLOCK / T;
+#ifndef ECAP
+#define ECAP 64
+#endif
+#ifndef TILE_1Q
+#define TILE_1Q 0   // 1: one quartet per lane inside the tile (small classes); 0: T row lanes per quartet
+#endif
+#ifndef RYS_LDS_MAX
+#define RYS_LDS_MAX 28672   // stage the class's Chebyshev table in LDS when it is at most this many bytes (nroots <= 5 in f64)
+#endif
+#ifndef NKS
+#define NKS 1       // ket tile pairs staged per iteration (lane-per-quartet mode: 2 or 4 where a tile pair has few candidates)
+#endif
+#ifndef MINW
+#define MINW 2      // waves/SIMD the register allocator leaves room for.  Never 1: builds with more than 256 registers per lane
+                    // (AGPR spill space) gave wrong results in a few classes (tools/verify_scheme.py)
+#endif
+#ifndef UNROLL_B
+#define UNROLL_B 1   // 1: unroll the root loop of phase B (loads of root r+1 overlap the products of root r)
+#endif
+#ifndef ST_LDS_MAX
+#define ST_LDS_MAX 40960   // double-buffer the TRR array (phase A of the next combination overlaps phase B) up to this size
+#endif
+constexpr int pick_nch()
+{
+    for (int n = 1; n <= NFK; n++)
+        if (NFK % n == 0 && (NFK / n) * NFL * EJ <= ECAP) return n;
+    return NFK;
+}
+constexpr int NCH = pick_nch();
+constexpr int CW = NFK / NCH;
+constexpr int E = EJ * CW * NFL;                     // integrals per lane and chunk: e = (cj * CW + kk) * NFL + cl
+constexpr int WI = TSI * NFI, WJ = TSJ * NFJ, WK = TSK * NFK, WL = TSL * NFL;
+constexpr int NT2 = (LIJ + 1) * (LKL + 1);
+constexpr int NJOB = G * 3 * NROOTS;                                      // phase-A jobs per step
+// The TRR array is single-buffered.  A double-buffered schedule (phase A of the next primitive combination issued before
+// phase B of the current one, one barrier per combination; code paths under NBUF > 1 below) measured 3-8 % faster, but it
+// gives wrong J/K in a few classes ((fd|fp), several g classes) on large inputs -- found by tools/verify_scheme.py, not
+// understood yet (no LDS race found by inspection; extra barriers do not cure it) -- so it stays disabled.
+#ifndef TRR_DOUBLE_BUFFER
+#define TRR_DOUBLE_BUFFER 0
+#endif
+constexpr int NBUF = (TRR_DOUBLE_BUFFER && !WSYNC && 2 * G * NROOTS * 3 * NT2 * (int)sizeof(real) <= ST_LDS_MAX) ? 2 : 1;
+static_assert(!WSYNC || (T <= 64 && !TILE_1Q), "WSYNC needs a quartet to fit one wave");
+static_assert(!CJR || !TILE_1Q, "CJR is a variant of the row-lane mode");
+#if WSYNC
+// ordering of LDS traffic inside one wave is kept by the hardware (one in-order DS queue per wave); the compiler only
+// has to keep the program order of the accesses
+#define STEP_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define STEP_SYNC() __syncthreads()
+#endif
+constexpr int RYS_TAB = (2 * NROOTS + 14) * NROOTS * NCOEF * 2;          // Chebyshev table of this class, in reals
+constexpr bool RYS_IN_LDS = RYS_TAB * (int)sizeof(real) <= RYS_LDS_MAX;
+static_assert(T <= TBLOCK && G >= 1 && NQ <= 65535, "tile geometry");
+static_assert((TSI + TSJ) * BASIS_STRIDE <= TBLOCK && (TSK + TSL) * BASIS_STRIDE <= TBLOCK, "shell rows of a tile pair are staged by one pass");
+static_assert(TBLOCK == 256 || !TILE_1Q, "the lane-per-quartet mode uses 256 threads");
+constexpr int KS_SHIFT = NKS == 1 ? 16 : NKS == 2 ? 15 : NKS == 4 ? 14 : 13;     // queue entry = candidate id | ket slot << KS_SHIFT
+static_assert(NKS == 1 || (TILE_1Q && (NKS == 2 || NKS == 4 || NKS == 8) && NQ <= (1 << KS_SHIFT)),
+              "several ket pairs per iteration: lane-per-quartet mode, 16-bit queue entries");
+
+// Timing-only ablations of the lane-per-quartet mode (WRONG results; tools/ablate.py): bit 0 no Rys table gather, bit 1 no
+// LDS atomics (sums kept alive in a register), bit 2 no density reads from LDS, bit 3 no integral evaluation, bit 4 no
+// compute phase at all (staging + screening + flush only)
+#ifndef ABL
+#define ABL 0
+#endif
+// Rys root `r` only (same tables and branches as rys_roots in jk_common.h)
+__device__ __forceinline__ void rys_root_one(real x, real theta, real omega, const int r, const real* cheb,
+                                             const real* __restrict__ large, real& root, real& weight)
+{
+    real tf = 1, stf = 1;
+    x *= theta;
+#if ABL & 1
+    root = x * real(1e-3) + real(0.3) * (r + 1); weight = real(0.5) + x * real(1e-4);
+    return;
+#endif
+#if RYS_LR
+    {
+        const real w2 = omega * omega;
+        tf = w2 / (w2 + theta);
+        x *= tf;
+        stf = sqrt(tf);
+    }
+#endif
+    if (x >= real(5 * NROOTS + 35)) {
+        const real isx = rsqrt(x);
+        root = large[2 * r] * isx * isx * tf;
+        weight = large[2 * r + 1] * isx * stf;
+        return;
+    }
+    const int it = (int)(x * real(0.4));
+    const real u = (x - real(2.5) * it) * real(0.8) - real(1);
+    const real u2 = u + u;
+    const real* c = cheb + (it * NROOTS + r) * (NCOEF * 2);
+    real br1 = 0, br2 = 0, bw1 = 0, bw2 = 0;
+#pragma unroll
+    for (int k = NCOEF - 1; k >= 1; k--) {
+        real t = c[2 * k] + u2 * br1 - br2; br2 = br1; br1 = t;
+        t = c[2 * k + 1] + u2 * bw1 - bw2; bw2 = bw1; bw1 = t;
+    }
+    root = (c[0] + u * br1 - br2) * tf;
+    weight = (c[1] + u * bw1 - bw2) * stf;
+}
+
+// Staging is split into "issue every global load" and "write LDS": all loads of a workgroup's staging step are in
+// flight together (one L2 round trip), instead of one round trip per tile as a load->store loop would cost.
+template <int NR, int NC>
+struct TileRegs { real v[(NR * NC + TBLOCK - 1) / TBLOCK]; };
+template <int NR, int NC>
+__device__ __forceinline__ void tile_load(TileRegs<NR, NC>& t, const real* __restrict__ dm, const int nao, const int r0,
+                                          const int c0, const int tid)
+{
+#pragma unroll
+    for (int u = 0; u < (NR * NC + TBLOCK - 1) / TBLOCK; u++) {
+        const int idx = tid + u * TBLOCK;
+        const int r = idx / NC, c = idx - r * NC;
+        t.v[u] = (idx < NR * NC && r0 + r < nao && c0 + c < nao) ? dm[(size_t)(r0 + r) * nao + c0 + c] : real(0);
+    }
+}
+template <int NR, int NC>
+__device__ __forceinline__ void tile_store(real* __restrict__ dst, const TileRegs<NR, NC>& t, const int tid)
+{
+#pragma unroll
+    for (int u = 0; u < (NR * NC + TBLOCK - 1) / TBLOCK; u++) {
+        const int idx = tid + u * TBLOCK;
+        if (idx < NR * NC) dst[idx] = t.v[u];
+    }
+}
+
+// add the tile to the global matrix and clear it (the thread that flushes an element is the one that clears it)
+__device__ __forceinline__ void flush_tile(double* __restrict__ src, double* __restrict__ out, const int nao,
+                                           const int r0, const int c0, const int NR, const int NC, const int tid)
+{
+    for (int idx = tid; idx < NR * NC; idx += TBLOCK) {
+        const int r = idx / NC, c = idx - r * NC;
+        const double v = src[idx];
+        if (v != 0.0) {
+            src[idx] = 0.0;
+#ifndef NO_FLUSH   // timing-only ablation (wrong results): no global atomics
+            if (r0 + r < nao && c0 + c < nao) atomic_add_f64(out + (size_t)(r0 + r) * nao + c0 + c, v);
+#endif
+        }
+    }
+}
+
+__device__ __forceinline__ void lds_add(double* p, double v) { atomicAdd(p, v); }   // ds_add_f64
+
+// candidate id -> ket shell index c inside the tile.  Lane-per-quartet mode skews c by (a + b + d): the 64 quartets of
+// a wave then spread evenly over the 16 targets of EVERY Fock sub-block (4 lanes per LDS address instead of 16 for
+// J_kl / K_ik / K_jk with the plain order); the row-lane mode keeps the plain order (its register accumulators
+// rely on consecutive quartets sharing the ket pair).
+#if TILE_1Q
+#define QC(craw, a, b, d) (((craw) + (a) + (b) + (d)) % TSK)
+#else
+#define QC(craw, a, b, d) (craw)
+#endif
+#ifndef STAMPS
+#define STAMPS 0    // diagnostic build: wave 0 adds the cycles it spends per phase to counter[-1-phase] (tools/stamps_profile.py)
+#endif
+#if STAMPS
+#define STAMP(k) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_last; st_last = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+#ifndef KNAME
+#define KNAME jk_tile
+#endif
+// The kernel arguments as they lie in the kernarg segment (same order / natural alignment as the signature below).
+// The ket loop re-reads the pointers it needs from there (scalar loads, K$ hits) at the start of its staging and
+// flush sections instead of keeping ~15 pointers + scalars live in SGPRs across the compute phase: the compute
+// phase is what runs out of SGPRs (exec-mask stack + uniform loop state), and every SGPR held for the staging code
+// is one more spilled to a VGPR lane there.
+#ifndef KARG_RELOAD
+#define KARG_RELOAD 1
+#endif
+#define AS4 __attribute__((address_space(4)))
+struct KArgs {
+    int nao; const real* basis; const real* dm; double* vj; double* vk; real omega; const int* tasks; int ntasks;
+    const unsigned* tpair_sh; const float* tpair_q; const float* q_cond; const float* log_dm; int nbas;
+    float cut_lo, cut_hi, log_max_dm; int n_dm; const real* rys_cheb; const real* rys_large;
+    unsigned long long* counter; const int* blk_index; const unsigned* tpair_ao; const unsigned* tpair_pp;
+    const real* pair_tab;
+};
+__device__ __forceinline__ const KArgs AS4* kargs()
+{
+    const KArgs AS4* p = (const KArgs AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));          // opaque: the loads below it stay where they are written
+    return p;
+}
+extern "C" __global__ void __launch_bounds__(TBLOCK, MINW)
+KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm, double* __restrict__ vj,
+        double* __restrict__ vk, const real omega, const int* __restrict__ tasks, const int ntasks,
+        const unsigned* __restrict__ tpair_sh, const float* __restrict__ tpair_q, const float* __restrict__ q_cond,
+        const float* __restrict__ log_dm, const int nbas, const float cut_lo, const float cut_hi,
+        const float log_max_dm, const int n_dm, const real* __restrict__ rys_cheb, const real* __restrict__ rys_large,
+        unsigned long long* __restrict__ counter, const int* __restrict__ blk_index,
+        const unsigned* __restrict__ tpair_ao, const unsigned* __restrict__ tpair_pp, const real* __restrict__ pair_tab)
+{
+    __shared__ unsigned s_nact[2];              // survivors of the current tile pair (double-buffered by iteration parity)
+    // NKS ket tile pairs are staged and screened per iteration (lane-per-quartet mode only): classes with few candidates
+    // per tile pair fill the 256 lanes from several ket pairs; queue entry = candidate id | ket slot << KS_SHIFT
+    __shared__ unsigned short s_act[NKS * NQ];  // their candidate ids, appended wave by wave
+    __shared__ real sDij[WJ * WI], sDkl[NKS * WL * WK], sDik[NKS * WI * WK], sDil[NKS * WI * WL], sDjk[NKS * WJ * WK], sDjl[NKS * WJ * WL];
+    __shared__ double sJij[WJ * WI], sJkl[NKS * WL * WK], sKik[NKS * WI * WK], sKil[NKS * WI * WL], sKjk[NKS * WJ * WK], sKjl[NKS * WJ * WL];
+#if !TILE_1Q
+    __shared__ real sT[NBUF * G * NROOTS * 3 * NT2];
+#endif
+    // shell rows of the four tiles and per-primitive-pair prefactors {c_a c_b K_ab, 1/(a+b), a+b}:
+    // every exp / reciprocal of the pair prefactors is evaluated once per tile pair, not once per quartet
+    __shared__ real sBas[(TSI + TSJ + NKS * (TSK + TSL)) * BASIS_STRIDE];
+    __shared__ real sPB[TSI * TSJ * 9 * 3], sPK[NKS * TSK * TSL * 9 * 3];
+    // Rys Chebyshev table of the class: every lane reads 28 coefficients of ITS OWN x-interval per root, i.e. 64
+    // different cache lines per wave instruction from global memory; from LDS the same gather costs a few cycles
+    __shared__ real sRys[RYS_IN_LDS ? RYS_TAB : 1];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+#if STAMPS
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- which (task row, bra pair, ket chunk): coarse index per 256 workgroups + one wave-wide probe of the
+    //      following rows (no chain of dependent loads as a binary search would need)
+    int row;
+    {
+        const int b = blockIdx.x;
+        row = blk_index[b >> 8];
+        for (;;) {
+            const int r = row + 1 + lane;
+            const bool p = r < ntasks && tasks[r * 8 + 5] <= b;
+            const int c = __popcll(__ballot(p));
+            row += c;
+            if (c < 64) break;
+        }
+        row = __builtin_amdgcn_readfirstlane(row);
+    }
+    STAMP(0);
+    const int* __restrict__ tk = tasks + row * 8;
+    const int ij0 = tk[0], kl0 = tk[2], nkl = tk[3], nchunk = tk[4], kchunk = tk[7] & 0xffff;
+    // small launches: the candidates of one (bra pair, ket chunk) are dealt to nsplit workgroups (contiguous id ranges)
+    const int nsplit = tk[7] >> 16;
+    const int lb0 = blockIdx.x - tk[5];
+    const int lb = lb0 / nsplit, sid = lb0 - lb * nsplit;
+    const int cand_lo = NQ * sid / nsplit, cand_hi = NQ * (sid + 1) / nsplit;
+    const int bij = lb / nchunk, ch = lb - bij * nchunk;
+    const int kt0 = ch * kchunk, kt1 = min(nkl, kt0 + kchunk);
+    const unsigned pij = tpair_sh[ij0 + bij], aoij = tpair_ao[ij0 + bij];
+    const float qij = tpair_q[ij0 + bij] + log_max_dm;
+    if (qij + tpair_q[kl0 + kt0] <= cut_lo) return;          // ket list is sorted: nothing in this chunk survives
+    const int ish0 = pij >> 16, jsh0 = pij & 0xffff;
+    const int i0 = aoij >> 16, j0 = aoij & 0xffff;           // first AO of the two tiles
+    constexpr int OFF_J = TSI * BASIS_STRIDE, OFF_K = (TSI + TSJ) * BASIS_STRIDE, OFF_L = (TSI + TSJ + TSK) * BASIS_STRIDE;
+    constexpr int KSTR = (TSK + TSL) * BASIS_STRIDE;          // ket slot stride in sBas
+    constexpr int NRYS = RYS_IN_LDS ? (RYS_TAB + TBLOCK - 1) / TBLOCK : 1;
+    // ---- bra side, once per workgroup: issue every load, then write LDS
+    {
+        real rb = 0, rrys[NRYS];
+        if (tid < (TSI + TSJ) * BASIS_STRIDE) {
+            const int sl = tid / BASIS_STRIDE, w = tid - sl * BASIS_STRIDE;
+            rb = basis[(sl < TSI ? ish0 + sl : jsh0 + sl - TSI) * BASIS_STRIDE + w];
+        }
+        // primitive-pair prefactors of the bra tile pair: a contiguous block of the per-geometry table
+        constexpr int NPB = (TSI * TSJ * 27 + TBLOCK - 1) / TBLOCK;
+        real rpb[NPB];
+        const real* __restrict__ ppb = pair_tab + (size_t)tpair_pp[ij0 + bij] * 27;
+#pragma unroll
+        for (int u = 0; u < NPB; u++) rpb[u] = tid + u * TBLOCK < TSI * TSJ * 27 ? ppb[tid + u * TBLOCK] : real(0);
+        if (RYS_IN_LDS) {
+#pragma unroll
+            for (int u = 0; u < NRYS; u++) rrys[u] = tid + u * TBLOCK < RYS_TAB ? rys_cheb[tid + u * TBLOCK] : real(0);
+        }
+#if DO_J
+        for (int n = tid; n < WJ * WI; n += TBLOCK) sJij[n] = 0;
+        for (int n = tid; n < NKS * WL * WK; n += TBLOCK) sJkl[n] = 0;
+#endif
+#if DO_K
+        for (int n = tid; n < NKS * WI * WK; n += TBLOCK) sKik[n] = 0;
+        for (int n = tid; n < NKS * WI * WL; n += TBLOCK) sKil[n] = 0;
+        for (int n = tid; n < NKS * WJ * WK; n += TBLOCK) sKjk[n] = 0;
+        for (int n = tid; n < NKS * WJ * WL; n += TBLOCK) sKjl[n] = 0;
+#endif
+        if (tid < 2) s_nact[tid] = 0;
+        if (tid < (TSI + TSJ) * BASIS_STRIDE) sBas[tid] = rb;
+#pragma unroll
+        for (int u = 0; u < NPB; u++)
+            if (tid + u * TBLOCK < TSI * TSJ * 27) sPB[tid + u * TBLOCK] = rpb[u];
+        if (RYS_IN_LDS) {
+#pragma unroll
+            for (int u = 0; u < NRYS; u++)
+                if (tid + u * TBLOCK < RYS_TAB) sRys[tid + u * TBLOCK] = rrys[u];
+        }
+    }
+    const real* cheb_tab = RYS_IN_LDS ? sRys : rys_cheb;
+    __syncthreads();            // counters and Fock tiles are clear before any wave appends / accumulates
+    STAMP(1);
+
+#if !TILE_1Q
+#if WSYNC
+    const int qslot = lane / T, slot = wave * GW + qslot, t = lane - qslot * T;
+    const bool lane_on = qslot < GW;
+#else
+    const int slot = tid / T, t = tid - slot * T;
+    const bool lane_on = slot < G;
+#endif
+#if CJR
+    const int ci = t, cj = 0;
+#else
+    const int ci = t / NFJ, cj = t - ci * NFJ;
+#endif
+    const int ibra[3] = {TI.x[ci], TI.y[ci], TI.z[ci]};
+    const int jbra[3] = {TJ.x[cj], TJ.y[cj], TJ.z[cj]};
+#endif
+    const size_t nao2 = (size_t)nao * nao;
+    unsigned nq_done = 0;
+    int parity = 0;
+
+#if KARG_RELOAD
+    for (int idm = 0; idm < kargs()->n_dm; idm++) {
+#else
+    for (int idm = 0; idm < n_dm; idm++) {
+        const real* __restrict__ D = dm + idm * nao2;
+#endif
+#if DO_J
+        __syncthreads();
+        {
+#if KARG_RELOAD
+            const KArgs AS4* kd = kargs();
+            const int nao = kd->nao;
+            const real* __restrict__ D = kd->dm + idm * ((size_t)nao * nao);
+#endif
+            TileRegs<WJ, WI> r;
+            tile_load(r, D, nao, j0, i0, tid);
+            tile_store(sDij, r, tid);
+        }
+        STAMP(2);
+#endif
+        for (int kt = kt0; kt < kt1; kt += NKS) {
+#if KARG_RELOAD
+            const KArgs AS4* ka = kargs();
+            const int nao = ka->nao, nbas = ka->nbas;
+            const float cut_lo = ka->cut_lo, cut_hi = ka->cut_hi;
+            const unsigned* __restrict__ tpair_sh = ka->tpair_sh;
+            const unsigned* __restrict__ tpair_ao = ka->tpair_ao;
+            const unsigned* __restrict__ tpair_pp = ka->tpair_pp;
+            const float* __restrict__ tpair_q = ka->tpair_q;
+            const float* __restrict__ q_cond = ka->q_cond;
+            const float* __restrict__ log_dm = ka->log_dm;
+            const real* __restrict__ basis = ka->basis;
+            const real* __restrict__ pair_tab = ka->pair_tab;
+            const real* __restrict__ D = ka->dm + idm * ((size_t)nao * nao);
+#endif
+            if (qij + tpair_q[kl0 + kt] <= cut_lo) break;
+            int ksh0s[NKS], lsh0s[NKS], k0s[NKS], l0s[NKS];
+            bool kval[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                // (the ket list is sorted by its bound: once a pair fails the cut every later one does)
+                kval[ks] = ks == 0 || (kt + ks < kt1 && qij + tpair_q[kl0 + kt + ks] > cut_lo);
+                const unsigned pkl = kval[ks] ? tpair_sh[kl0 + kt + ks] : 0u, aokl = kval[ks] ? tpair_ao[kl0 + kt + ks] : 0u;
+                ksh0s[ks] = pkl >> 16; lsh0s[ks] = pkl & 0xffff;
+                k0s[ks] = aokl >> 16; l0s[ks] = aokl & 0xffff;
+            }
+            parity ^= 1;
+            // index arithmetic of the staging / flush loops is re-derived from an opaque copy of the thread id: keeps
+            // the (cheap) loop-invariant addresses from being hoisted over the compute phase and spilled there
+            int tid_s = tid;
+            asm volatile("" : "+v"(tid_s));
+#define tid tid_s
+            if (tid == 0) s_nact[parity ^ 1] = 0;          // next iteration's counter (last read before this point)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                if (!kval[ks]) continue;
+                const int ksh0 = ksh0s[ks], lsh0 = lsh0s[ks], k0 = k0s[ks], l0 = l0s[ks];
+                // ---- issue: ket shell rows, primitive-pair inputs, five density sub-blocks
+                real rb = 0;
+                if (tid < (TSK + TSL) * BASIS_STRIDE) {
+                    const int sl = tid / BASIS_STRIDE, w = tid - sl * BASIS_STRIDE;
+                    rb = basis[(sl < TSK ? ksh0 + sl : lsh0 + sl - TSK) * BASIS_STRIDE + w];
+                }
+                constexpr int NPK = (TSK * TSL * 27 + TBLOCK - 1) / TBLOCK;
+                real rpk[NPK];
+                const real* __restrict__ ppk = pair_tab + (size_t)tpair_pp[kl0 + kt + ks] * 27;
+#pragma unroll
+                for (int u = 0; u < NPK; u++) rpk[u] = tid + u * TBLOCK < TSK * TSL * 27 ? ppk[tid + u * TBLOCK] : real(0);
+#if DO_J
+                TileRegs<WL, WK> rkl;
+                tile_load(rkl, D, nao, l0, k0, tid);
+#endif
+#if DO_K
+                TileRegs<WI, WK> rik;
+                TileRegs<WI, WL> ril;
+                TileRegs<WJ, WK> rjk;
+                TileRegs<WJ, WL> rjl;
+                tile_load(rik, D, nao, i0, k0, tid);
+                tile_load(ril, D, nao, i0, l0, tid);
+                tile_load(rjk, D, nao, j0, k0, tid);
+                tile_load(rjl, D, nao, j0, l0, tid);
+#endif
+                STAMP(3);
+                // ---- per-quartet screening of the NQ candidates of the tile pair (wave64 ballots); every wave appends
+                //      its survivors to the queue through one LDS counter
+#pragma unroll 2
+                for (int cand0 = cand_lo; cand0 < cand_hi; cand0 += TBLOCK) {
+                    const int cd = cand0 + tid;
+                    bool keep = false;
+                    if (cd < cand_hi) {
+                        const int a = cd % TSI, b = (cd / TSI) % TSJ, d = (cd / (TSI * TSJ)) % TSL;
+                        const int c = QC(cd / (TSI * TSJ * TSL), a, b, d);
+                        const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
+                        if (ish >= jsh && ksh >= lsh && ish * nbas + jsh >= ksh * nbas + lsh) {
+                            const float sq = q_cond[ish * nbas + jsh] + q_cond[ksh * nbas + lsh];
+                            float sd = -36.8f;
+#if DO_K
+                            sd = fmaxf(sd, log_dm[ish * nbas + ksh]);
+                            sd = fmaxf(sd, log_dm[jsh * nbas + ksh]);
+                            sd = fmaxf(sd, log_dm[ish * nbas + lsh]);
+                            sd = fmaxf(sd, log_dm[jsh * nbas + lsh]);
+#endif
+#if DO_J
+                            sd = fmaxf(sd, log_dm[ish * nbas + jsh]);
+                            sd = fmaxf(sd, log_dm[ksh * nbas + lsh]);
+#endif
+                            const float dq = sq + sd;
+                            keep = dq > cut_lo && dq <= cut_hi;
+                        }
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (m) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&s_nact[parity], (unsigned)__popcll(m));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (keep) s_act[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(cd | (ks << KS_SHIFT));
+                    }
+                }
+                // ---- write LDS
+                if (tid < (TSK + TSL) * BASIS_STRIDE) sBas[OFF_K + ks * KSTR + tid] = rb;
+#pragma unroll
+                for (int u = 0; u < NPK; u++)
+                    if (tid + u * TBLOCK < TSK * TSL * 27) sPK[ks * (TSK * TSL * 27) + tid + u * TBLOCK] = rpk[u];
+#if DO_J
+                tile_store(sDkl + ks * (WL * WK), rkl, tid);
+#endif
+#if DO_K
+                tile_store(sDik + ks * (WI * WK), rik, tid);
+                tile_store(sDil + ks * (WI * WL), ril, tid);
+                tile_store(sDjk + ks * (WJ * WK), rjk, tid);
+                tile_store(sDjl + ks * (WJ * WL), rjl, tid);
+#endif
+            }
+#undef tid
+            const int ksh0 = ksh0s[0], lsh0 = lsh0s[0], k0 = k0s[0], l0 = l0s[0];      // (row-lane mode: one ket pair)
+            STAMP(4);
+            __syncthreads();
+            STAMP(5);
+            const int nact = __builtin_amdgcn_readfirstlane((int)s_nact[parity]);
+            if (nact == 0) continue;
+            const int npi = __builtin_amdgcn_readfirstlane((int)sBas[10]), npj = __builtin_amdgcn_readfirstlane((int)sBas[OFF_J + 10]);
+            const int npk = __builtin_amdgcn_readfirstlane((int)sBas[OFF_K + 10]), npl = __builtin_amdgcn_readfirstlane((int)sBas[OFF_L + 10]);
+            if (idm == 0) nq_done += nact;
+
+#if TILE_1Q
+            // ---------------- one quartet per lane: everything in registers, then LDS Fock tiles
+#if ABL & 2
+            double abl_sink = 0;
+#define LDS_ADD(p, v) (abl_sink += (double)(v))
+#else
+#define LDS_ADD(p, v) lds_add(p, v)
+#endif
+#if ABL & 4
+#define DLD(x) real(0.37)
+#else
+#define DLD(x) (x)
+#endif
+            for (int q1 = tid; q1 < ((ABL & 16) ? 0 : nact); q1 += TBLOCK) {
+                const int qe = s_act[q1];
+                const int ks = NKS > 1 ? qe >> KS_SHIFT : 0, qd = NKS > 1 ? qe & ((1 << KS_SHIFT) - 1) : qe;
+                const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
+                int kshb = ksh0s[0], lshb = lsh0s[0];
+#pragma unroll
+                for (int u = 1; u < NKS; u++)
+                    if (ks == u) { kshb = ksh0s[u]; lshb = lsh0s[u]; }
+                const int ish = ish0 + a, jsh = jsh0 + b, ksh = kshb + c, lsh = lshb + d;
+                const real* bi = sBas + a * BASIS_STRIDE;
+                const real* bj = sBas + OFF_J + b * BASIS_STRIDE;
+                const real* bk = sBas + OFF_K + ks * KSTR + c * BASIS_STRIDE;
+                const real* bl = sBas + OFF_L + ks * KSTR + d * BASIS_STRIDE;
+                const real* pb = sPB + (a * TSJ + b) * 27;
+                const real* pk = sPK + (ks * TSK * TSL + c * TSL + d) * 27;
+                const real rix = bi[0], riy = bi[1], riz = bi[2];
+                const real rkx = bk[0], rky = bk[1], rkz = bk[2];
+                const real rij[3] = {bj[0] - rix, bj[1] - riy, bj[2] - riz};
+                const real rkl[3] = {bl[0] - rkx, bl[1] - rky, bl[2] - rkz};
+                real fac = real(34.98683665524972497);
+                if (ish == jsh) fac *= real(0.5);
+                if (ksh == lsh) fac *= real(0.5);
+                if (ish == ksh && jsh == lsh) fac *= real(0.5);
+                real I[NINT];
+#pragma unroll
+                for (int n = 0; n < NINT; n++) I[n] = 0;
+#if ABL & 8
+#pragma unroll
+                for (int n = 0; n < NINT; n++) I[n] = fac * (rij[0] + real(n + 1)) * rkl[1];
+#endif
+                for (int kp = 0; kp < ((ABL & 8) ? 0 : npk); kp++)
+                for (int lp = 0; lp < npl; lp++) {
+                    const real ckcl = pk[(kp * 3 + lp) * 3], inv_akl = pk[(kp * 3 + lp) * 3 + 1], akl = pk[(kp * 3 + lp) * 3 + 2];
+                    const real al_akl = bl[5 + 2 * lp] * inv_akl;
+                    for (int ip = 0; ip < npi; ip++)
+                    for (int jp = 0; jp < npj; jp++) {
+                        const real inv_aij = pb[(ip * 3 + jp) * 3 + 1], aij = pb[(ip * 3 + jp) * 3 + 2];
+                        const real aj_aij = bj[5 + 2 * jp] * inv_aij;
+                        const real cicj = fac * pb[(ip * 3 + jp) * 3];
+                        const real rpa[3] = {rij[0] * aj_aij, rij[1] * aj_aij, rij[2] * aj_aij};
+                        const real rqc[3] = {rkl[0] * al_akl, rkl[1] * al_akl, rkl[2] * al_akl};
+                        const real rpq[3] = {rpa[0] + rix - rqc[0] - rkx, rpa[1] + riy - rqc[1] - rky,
+                                             rpa[2] + riz - rqc[2] - rkz};
+                        const real rr = rpq[0] * rpq[0] + rpq[1] * rpq[1] + rpq[2] * rpq[2];
+                        const real sinv = fast_rsqrt(aij + akl);
+                        const real inv = sinv * sinv;
+                        const real theta = aij * akl * inv;
+                        const real gy0 = cicj * inv_aij * inv_akl * sinv;
+#pragma clang loop unroll(disable)
+                        for (int ir = 0; ir < NROOTS; ir++) {
+                            // one root at a time: evaluating all roots at once keeps 28 table coefficients per root live
+                            real t2, wt;
+                            rys_root_one(rr, theta, omega, ir, cheb_tab, rys_large, t2, wt);
+                            const real rt_aa = t2 * inv;
+                            const real rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
+                            const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
+                            const real b01 = real(0.5) * inv_akl * (real(1) - rt_akl);
+                            const real b00 = real(0.5) * rt_aa;
+                            real gx[GSIZE], gy[GSIZE], gz[GSIZE];
+                            axis_integrals(ckcl, rpa[0] - rt_aij * rpq[0], rqc[0] + rt_akl * rpq[0], b10, b01, b00, rij[0], rkl[0], gx);
+                            axis_integrals(gy0, rpa[1] - rt_aij * rpq[1], rqc[1] + rt_akl * rpq[1], b10, b01, b00, rij[1], rkl[1], gy);
+                            axis_integrals(wt, rpa[2] - rt_aij * rpq[2], rqc[2] + rt_akl * rpq[2], b10, b01, b00, rij[2], rkl[2], gz);
+#pragma unroll
+                            for (int i = 0; i < NFI; i++)
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                            for (int k = 0; k < NFK; k++)
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) {
+                                const int ax = TI.x[i] * GS_I + TJ.x[j] * GS_J + TK.x[k] * GS_K + TL.x[l];
+                                const int ay = TI.y[i] * GS_I + TJ.y[j] * GS_J + TK.y[k] * GS_K + TL.y[l];
+                                const int az = TI.z[i] * GS_I + TJ.z[j] * GS_J + TK.z[k] * GS_K + TL.z[l];
+                                I[((i * NFJ + j) * NFK + k) * NFL + l] += gx[ax] * gy[ay] * gz[az];
+                            }
+                        }
+                    }
+                }
+                const int iA = a * NFI, jA = b * NFJ, kA = c * NFK, lA = d * NFL;
+                // ket-slot views of the ket-dependent tiles
+                const real* sDkl_q = sDkl + ks * (WL * WK); const real* sDik_q = sDik + ks * (WI * WK);
+                const real* sDil_q = sDil + ks * (WI * WL); const real* sDjk_q = sDjk + ks * (WJ * WK);
+                const real* sDjl_q = sDjl + ks * (WJ * WL);
+                double* sJkl_q = sJkl + ks * (WL * WK); double* sKik_q = sKik + ks * (WI * WK);
+                double* sKil_q = sKil + ks * (WI * WL); double* sKjk_q = sKjk + ks * (WJ * WK);
+                double* sKjl_q = sKjl + ks * (WJ * WL);
+#if DO_J
+                {
+                    real jkl[NFK * NFL], dkl[NFK * NFL];
+#pragma unroll
+                    for (int k = 0; k < NFK; k++)
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) { jkl[k * NFL + l] = 0; dkl[k * NFL + l] = DLD(sDkl_q[(lA + l) * WK + kA + k]); }
+#pragma unroll
+                    for (int i = 0; i < NFI; i++)
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) {
+                            const real dij = DLD(sDij[(jA + j) * WI + iA + i]);
+                            real s = 0;
+#pragma unroll
+                            for (int n = 0; n < NFK * NFL; n++) {
+                                const real v = I[(i * NFJ + j) * NFK * NFL + n];
+                                s += v * dkl[n];
+                                jkl[n] += v * dij;
+                            }
+                            LDS_ADD(&sJij[(jA + j) * WI + iA + i], (double)s);
+                        }
+#pragma unroll
+                    for (int k = 0; k < NFK; k++)
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sJkl_q[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
+                }
+#endif
+#if DO_K
+                {
+                    real kjk[NFJ * NFK], kjl[NFJ * NFL], djk[NFJ * NFK], djl[NFJ * NFL];
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) { kjk[j * NFK + k] = 0; djk[j * NFK + k] = DLD(sDjk_q[(jA + j) * WK + kA + k]); }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) { kjl[j * NFL + l] = 0; djl[j * NFL + l] = DLD(sDjl_q[(jA + j) * WL + lA + l]); }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NFI; i++) {
+                        real kik[NFK], kil[NFL], dik[NFK], dil[NFL];
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) { kik[k] = 0; dik[k] = DLD(sDik_q[(iA + i) * WK + kA + k]); }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) { kil[l] = 0; dil[l] = DLD(sDil_q[(iA + i) * WL + lA + l]); }
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                            for (int k = 0; k < NFK; k++)
+#pragma unroll
+                                for (int l = 0; l < NFL; l++) {
+                                    const real v = I[((i * NFJ + j) * NFK + k) * NFL + l];
+                                    kik[k] += v * djl[j * NFL + l];
+                                    kil[l] += v * djk[j * NFK + k];
+                                    kjk[j * NFK + k] += v * dil[l];
+                                    kjl[j * NFL + l] += v * dik[k];
+                                }
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) LDS_ADD(&sKik_q[(iA + i) * WK + kA + k], (double)kik[k]);
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sKil_q[(iA + i) * WL + lA + l], (double)kil[l]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) LDS_ADD(&sKjk_q[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sKjl_q[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
+                    }
+                }
+#endif
+            }
+#if ABL & 2
+            if (abl_sink == 1.2345e300) sJij[0] = abl_sink;
+#endif
+#else   // ---------------- row-lane mode
+            const int per = (nact + G - 1) / G;
+            const int ncomb = npk * npl * npi * npj;
+            const int nitem = per * ncomb;            // (step, primitive combination) pairs, flattened
+            // phase A of item `m` into buffer m % NBUF
+            auto phase_a = [&](const int m) {
+                const int step = m / ncomb;
+                int cmb = m - step * ncomb;
+                const int jp = cmb % npj; cmb /= npj;
+                const int ip = cmb % npi; cmb /= npi;
+                const int lp = cmb % npl;
+                const int kp = cmb / npl;
+                real* __restrict__ buf = sT + (NBUF > 1 ? (m & 1) : 0) * (G * NROOTS * 3 * NT2);
+#if WSYNC
+                for (int job = lane; job < GW * 3 * NROOTS; job += 64) {
+                    const int sl = job / (3 * NROOTS), rem = job - sl * (3 * NROOTS);
+                    const int sa = wave * GW + sl;
+#else
+                for (int job = tid; job < NJOB; job += TBLOCK) {
+                    const int sa = job / (3 * NROOTS), rem = job - sa * (3 * NROOTS);
+#endif
+                    const int r = rem / 3, ax = rem - r * 3;
+                    const int qa = sa * per + step;
+                    if (qa >= nact) continue;
+                    const int qd = s_act[qa];
+                    const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
+                    const real* bi = sBas + a * BASIS_STRIDE;
+                    const real* bj = sBas + OFF_J + b * BASIS_STRIDE;
+                    const real* bk = sBas + OFF_K + c * BASIS_STRIDE;
+                    const real* bl = sBas + OFF_L + d * BASIS_STRIDE;
+                    const real* pb = sPB + (a * TSJ + b) * 27 + (ip * 3 + jp) * 3;
+                    const real* pk = sPK + (c * TSL + d) * 27 + (kp * 3 + lp) * 3;
+                    const real ckcl = pk[0], inv_akl = pk[1], akl = pk[2];
+                    const real cicj = pb[0], inv_aij = pb[1], aij = pb[2];
+                    const real al_akl = bl[5 + 2 * lp] * inv_akl, aj_aij = bj[5 + 2 * jp] * inv_aij;
+                    const real rij0 = bj[0] - bi[0], rij1 = bj[1] - bi[1], rij2 = bj[2] - bi[2];
+                    const real rkl0 = bl[0] - bk[0], rkl1 = bl[1] - bk[1], rkl2 = bl[2] - bk[2];
+                    const real rpq0 = rij0 * aj_aij + bi[0] - rkl0 * al_akl - bk[0];
+                    const real rpq1 = rij1 * aj_aij + bi[1] - rkl1 * al_akl - bk[1];
+                    const real rpq2 = rij2 * aj_aij + bi[2] - rkl2 * al_akl - bk[2];
+                    const real rr = rpq0 * rpq0 + rpq1 * rpq1 + rpq2 * rpq2;
+                    const real sinv = fast_rsqrt(aij + akl);
+                    const real inv = sinv * sinv;
+                    const real theta = aij * akl * inv;
+                    real t2, wt;
+                    rys_root_one(rr, theta, omega, r, cheb_tab, rys_large, t2, wt);
+                    const real rt_aa = t2 * inv;
+                    const real rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
+                    const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
+                    const real b01 = real(0.5) * inv_akl * (real(1) - rt_akl);
+                    const real b00 = real(0.5) * rt_aa;
+                    const real rij_a = ax == 0 ? rij0 : ax == 1 ? rij1 : rij2;
+                    const real rkl_a = ax == 0 ? rkl0 : ax == 1 ? rkl1 : rkl2;
+                    const real rpq_a = ax == 0 ? rpq0 : ax == 1 ? rpq1 : rpq2;
+                    const real c0 = rij_a * aj_aij - rt_aij * rpq_a;
+                    const real cp = rkl_a * al_akl + rt_akl * rpq_a;
+                    real g0;
+                    if (ax == 0) g0 = ckcl;
+                    else if (ax == 1) {
+                        const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
+                        real fac = real(34.98683665524972497);
+                        if (ish == jsh) fac *= real(0.5);
+                        if (ksh == lsh) fac *= real(0.5);
+                        if (ish == ksh && jsh == lsh) fac *= real(0.5);
+                        g0 = fac * cicj * inv_aij * inv_akl * sinv;
+                    } else g0 = wt;
+                    real tt[LIJ + 1][LKL + 1];
+                    tt[0][0] = g0;
+                    if (LIJ > 0) {
+                        tt[1][0] = c0 * g0;
+#pragma unroll
+                        for (int q = 1; q < LIJ; q++) tt[q + 1][0] = c0 * tt[q][0] + q * b10 * tt[q - 1][0];
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < LKL; cc++) {
+#pragma unroll
+                        for (int q = 0; q <= LIJ; q++) {
+                            real v = cp * tt[q][cc];
+                            if (cc > 0) v += cc * b01 * tt[q][cc - 1];
+                            if (q > 0) v += q * b00 * tt[q - 1][cc];
+                            tt[q][cc + 1] = v;
+                        }
+                    }
+                    real* __restrict__ dst = buf + (sa * NROOTS * 3 + r * 3 + ax) * NT2;
+#pragma unroll
+                    for (int q = 0; q <= LIJ; q++)
+#pragma unroll
+                        for (int cc = 0; cc <= LKL; cc++) dst[q * (LKL + 1) + cc] = tt[q][cc];
+                }
+            };
+
+#pragma unroll
+            for (int CH = 0; CH < NCH; CH++) {
+                // register accumulators carried across consecutive quartets of this lane that share the destination block
+                double jkl_acc[CW * NFL], kjk_acc[EJ * CW], kjl_acc[EJ * NFL];
+#pragma unroll
+                for (int e = 0; e < CW * NFL; e++) jkl_acc[e] = 0;
+#pragma unroll
+                for (int n = 0; n < EJ * CW; n++) kjk_acc[n] = 0;
+#pragma unroll
+                for (int n = 0; n < EJ * NFL; n++) kjl_acc[n] = 0;
+
+                int item = 0;
+                if (NBUF > 1) {
+                    phase_a(0);
+                    STEP_SYNC();
+                }
+                for (int step = 0; step < per; step++) {
+                    const int qi = slot * per + step;
+                    const bool on = lane_on && qi < nact;
+                    int a = 0, b = 0, c = 0, d = 0;
+                    if (on) {
+                        const int qd = s_act[qi];
+                        a = qd % TSI; b = (qd / TSI) % TSJ; d = (qd / (TSI * TSJ)) % TSL; c = QC(qd / (TSI * TSJ * TSL), a, b, d);
+                    }
+                    const real* bi = sBas + a * BASIS_STRIDE;
+                    const real* bj = sBas + OFF_J + b * BASIS_STRIDE;
+                    const real* bk = sBas + OFF_K + c * BASIS_STRIDE;
+                    const real* bl = sBas + OFF_L + d * BASIS_STRIDE;
+                    const real rij[3] = {bj[0] - bi[0], bj[1] - bi[1], bj[2] - bi[2]};
+                    const real rkl[3] = {bl[0] - bk[0], bl[1] - bk[1], bl[2] - bk[2]};
+
+                    // bra HRR as a weighted sum over TRR rows: g(i,j) = sum_m C(j,m) (Ri-Rj)^(j-m) t[i+m]
+                    real wb[3][LJ + 1];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) {
+                        const int ja = jbra[ax];
+                        const real ab = -rij[ax];
+                        real pw = 1;      // ab^(ja-m), built downwards from m = ja
+                        int binom = 1;    // C(ja, m)
+#pragma unroll
+                        for (int m = LJ; m >= 0; m--) {
+                            if (m > ja) { wb[ax][m] = 0; continue; }
+                            wb[ax][m] = pw * binom;
+                            pw *= ab;
+                            binom = binom * m / (ja - m + 1);
+                        }
+                    }
+
+                    real acc[E];
+#pragma unroll
+                    for (int e = 0; e < E; e++) acc[e] = 0;
+
+                    for (int cmb = 0; cmb < ncomb; cmb++, item++) {
+                        STAMP(13);
+                        if (NBUF > 1) {
+                            if (item + 1 < nitem) phase_a(item + 1);
+                        } else {
+                            phase_a(item);
+                            STEP_SYNC();
+                        }
+                        STAMP(10);
+                        // ---------------- phase B: row lanes: own bra slice, ket HRR, integral accumulation
+                        if (on) {
+                            const real* __restrict__ myT = sT + (NBUF > 1 ? (item & 1) : 0) * (G * NROOTS * 3 * NT2) +
+                                                           slot * (NROOTS * 3 * NT2);
+#if UNROLL_B
+#pragma unroll
+#else
+#pragma clang loop unroll(disable)
+#endif
+                            for (int r = 0; r < NROOTS; r++) {
+#if CJR
+                                // bra HRR for every j power and the ket HRR in registers: gk[axis][j][k][l]
+                                real gk[3][LJ + 1][LK + 1][LL + 1];
+#pragma unroll
+                                for (int ax = 0; ax < 3; ax++) {
+                                    const real* tp = myT + (r * 3 + ax) * NT2 + ibra[ax] * (LKL + 1);
+                                    real h[LJ + 1][LKL + 1];
+#pragma unroll
+                                    for (int m = 0; m <= LJ; m++)
+#pragma unroll
+                                        for (int cc = 0; cc <= LKL; cc++) h[m][cc] = tp[m * (LKL + 1) + cc];
+#pragma unroll
+                                    for (int j = 0; j <= LJ; j++) {
+                                        real w[LKL + 1];
+#pragma unroll
+                                        for (int cc = 0; cc <= LKL; cc++) w[cc] = h[0][cc];
+#pragma unroll
+                                        for (int l = 0; l <= LL; l++) {
+#pragma unroll
+                                            for (int k = 0; k <= LK; k++) gk[ax][j][k][l] = w[k];
+                                            if (l < LL) {
+#pragma unroll
+                                                for (int cc = 0; cc < LKL - l; cc++) w[cc] = w[cc + 1] - rkl[ax] * w[cc];
+                                            }
+                                        }
+                                        if (j < LJ) {
+#pragma unroll
+                                            for (int m = 0; m < LJ - j; m++)
+#pragma unroll
+                                                for (int cc = 0; cc <= LKL; cc++) h[m][cc] = h[m + 1][cc] - rij[ax] * h[m][cc];
+                                        }
+                                    }
+                                }
+#pragma unroll
+                                for (int oj = 0; oj < NFJ; oj++)
+#pragma unroll
+                                    for (int kk = 0; kk < CW; kk++)
+#pragma unroll
+                                        for (int cl = 0; cl < NFL; cl++) {
+                                            const int ck = CH * CW + kk;
+                                            acc[(oj * CW + kk) * NFL + cl] += gk[0][TJ.x[oj]][TK.x[ck]][TL.x[cl]] *
+                                                                              gk[1][TJ.y[oj]][TK.y[ck]][TL.y[cl]] *
+                                                                              gk[2][TJ.z[oj]][TK.z[ck]][TL.z[cl]];
+                                        }
+                            }
+#else
+                                real gk[3][LK + 1][LL + 1];
+#pragma unroll
+                                for (int ax = 0; ax < 3; ax++) {
+                                    const real* __restrict__ tp = myT + (r * 3 + ax) * NT2 + ibra[ax] * (LKL + 1);
+                                    real w[LKL + 1];
+#pragma unroll
+                                    for (int cc = 0; cc <= LKL; cc++) w[cc] = wb[ax][0] * tp[cc];
+#pragma unroll
+                                    for (int m = 1; m <= LJ; m++)
+#pragma unroll
+                                        for (int cc = 0; cc <= LKL; cc++) w[cc] += wb[ax][m] * tp[m * (LKL + 1) + cc];
+#pragma unroll
+                                    for (int l = 0; l <= LL; l++) {
+#pragma unroll
+                                        for (int k = 0; k <= LK; k++) gk[ax][k][l] = w[k];
+                                        if (l < LL) {
+#pragma unroll
+                                            for (int cc = 0; cc < LKL - l; cc++) w[cc] = w[cc + 1] - rkl[ax] * w[cc];
+                                        }
+                                    }
+                                }
+#pragma unroll
+                                for (int kk = 0; kk < CW; kk++)
+#pragma unroll
+                                    for (int cl = 0; cl < NFL; cl++) {
+                                        const int ck = CH * CW + kk;
+                                        acc[kk * NFL + cl] += gk[0][TK.x[ck]][TL.x[cl]] * gk[1][TK.y[ck]][TL.y[cl]] *
+                                                              gk[2][TK.z[ck]][TL.z[cl]];
+                                    }
+                            }
+#endif
+                        }
+                        STAMP(11);
+                        STEP_SYNC();
+                        STAMP(12);
+                    }
+
+                    // ---------------- contraction with the density sub-blocks.  All LDS reads and arithmetic first, every
+                    // LDS atomic of the step at the end: the DS queue of a CU is in order, so a read issued behind a
+                    // same-address f64 atomic waits for its serialised lanes (~9 cycles each, tools/micro/lds_atomic_bench.hip);
+                    // issued last, the atomics drain under the next step's arithmetic.
+                    const int iA = a * NFI + ci, jA = b * NFJ + cj;
+                    const int kb = c * NFK + CH * CW, lbs = d * NFL;
+                    // does the next quartet of this lane still belong to the same (k,l) / (j,k) / (j,l) block?
+                    bool keep_kl = false, keep_jk = false, keep_jl = false;
+                    if (on && step + 1 < per && qi + 1 < nact) {
+                        const int q2 = s_act[qi + 1];
+                        const int a2 = q2 % TSI, b2 = (q2 / TSI) % TSJ, d2 = (q2 / (TSI * TSJ)) % TSL;
+                        const int c2 = QC(q2 / (TSI * TSJ * TSL), a2, b2, d2);
+                        keep_kl = c2 == c && d2 == d;
+                        keep_jk = b2 == b && c2 == c;
+                        keep_jl = b2 == b && d2 == d;
+                    }
+#if CJR
+                    if (on) {
+                        // lane = bra component ci, registers = (cj, k, l): J_ij, K_ik, K_il are complete in the lane
+                        const int jA0 = b * NFJ;
+                        real s_ij[NFJ], s_ik[CW], s_il[NFL];
+#pragma unroll
+                        for (int kk = 0; kk < CW; kk++) s_ik[kk] = 0;
+#pragma unroll
+                        for (int cl = 0; cl < NFL; cl++) s_il[cl] = 0;
+#pragma unroll
+                        for (int oj = 0; oj < NFJ; oj++) {
+                            real sj = 0;
+#if DO_J
+                            const real dij = sDij[(jA0 + oj) * WI + iA];
+#endif
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++) {
+#if DO_K
+                                const real djk = sDjk[(jA0 + oj) * WK + kb + kk], dik = sDik[iA * WK + kb + kk];
+                                real s_jk = 0;
+#endif
+#pragma unroll
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    const real v = acc[(oj * CW + kk) * NFL + cl];
+#if DO_J
+                                    sj += v * sDkl[(lbs + cl) * WK + kb + kk];
+                                    jkl_acc[kk * NFL + cl] += (double)(v * dij);
+#endif
+#if DO_K
+                                    s_ik[kk] += v * sDjl[(jA0 + oj) * WL + lbs + cl];
+                                    s_il[cl] += v * djk;
+                                    s_jk += v * sDil[iA * WL + lbs + cl];
+                                    kjl_acc[oj * NFL + cl] += (double)(v * dik);
+#endif
+                                }
+#if DO_K
+                                kjk_acc[oj * CW + kk] += (double)s_jk;
+#endif
+                            }
+                            s_ij[oj] = sj;
+                        }
+                        // ---- atomics of the step
+#if DO_J
+#pragma unroll
+                        for (int oj = 0; oj < NFJ; oj++) lds_add(&sJij[(jA0 + oj) * WI + iA], (double)s_ij[oj]);
+                        if (!keep_kl) {
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++)
+#pragma unroll
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    lds_add(&sJkl[(lbs + cl) * WK + kb + kk], jkl_acc[kk * NFL + cl]);
+                                    jkl_acc[kk * NFL + cl] = 0;
+                                }
+                        }
+#endif
+#if DO_K
+#pragma unroll
+                        for (int kk = 0; kk < CW; kk++) lds_add(&sKik[iA * WK + kb + kk], (double)s_ik[kk]);
+#pragma unroll
+                        for (int cl = 0; cl < NFL; cl++) lds_add(&sKil[iA * WL + lbs + cl], (double)s_il[cl]);
+                        if (!keep_jk) {
+#pragma unroll
+                            for (int oj = 0; oj < NFJ; oj++)
+#pragma unroll
+                                for (int kk = 0; kk < CW; kk++) {
+                                    lds_add(&sKjk[(jA0 + oj) * WK + kb + kk], kjk_acc[oj * CW + kk]);
+                                    kjk_acc[oj * CW + kk] = 0;
+                                }
+                        }
+                        if (!keep_jl) {
+#pragma unroll
+                            for (int oj = 0; oj < NFJ; oj++)
+#pragma unroll
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    lds_add(&sKjl[(jA0 + oj) * WL + lbs + cl], kjl_acc[oj * NFL + cl]);
+                                    kjl_acc[oj * NFL + cl] = 0;
+                                }
+                        }
+#endif
+                    }
+                }
+            }
+#else
+                    real s_ij = 0, s_ik[CW], kil[NFL];
+                    if (on) {
+#if DO_J
+                        {
+                            const real dij = sDij[jA * WI + iA];
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++)
+#pragma unroll
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    const real v = acc[kk * NFL + cl];
+                                    s_ij += v * sDkl[(lbs + cl) * WK + kb + kk];
+                                    jkl_acc[kk * NFL + cl] += (double)(v * dij);
+                                }
+                        }
+#endif
+#if DO_K
+#pragma unroll
+                        for (int cl = 0; cl < NFL; cl++) kil[cl] = 0;
+#pragma unroll
+                        for (int kk = 0; kk < CW; kk++) {
+                            real sk = 0, s_jk = 0;
+                            const real djk = sDjk[jA * WK + kb + kk], dik = sDik[iA * WK + kb + kk];
+#pragma unroll
+                            for (int cl = 0; cl < NFL; cl++) {
+                                const real v = acc[kk * NFL + cl];
+                                sk += v * sDjl[jA * WL + lbs + cl];
+                                s_jk += v * sDil[iA * WL + lbs + cl];
+                                kil[cl] += v * djk;
+                                kjl_acc[cl] += (double)(v * dik);
+                            }
+                            s_ik[kk] = sk;
+                            kjk_acc[kk] += (double)s_jk;
+                        }
+#endif
+                        // ---- atomics of the step
+#if DO_J
+                        lds_add(&sJij[jA * WI + iA], (double)s_ij);
+                        if (!keep_kl) {
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++)
+#pragma unroll
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    lds_add(&sJkl[(lbs + cl) * WK + kb + kk], jkl_acc[kk * NFL + cl]);
+                                    jkl_acc[kk * NFL + cl] = 0;
+                                }
+                        }
+#endif
+#if DO_K
+#pragma unroll
+                        for (int kk = 0; kk < CW; kk++) lds_add(&sKik[iA * WK + kb + kk], (double)s_ik[kk]);
+#pragma unroll
+                        for (int cl = 0; cl < NFL; cl++) lds_add(&sKil[iA * WL + lbs + cl], (double)kil[cl]);
+                        if (!keep_jk) {
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++) { lds_add(&sKjk[jA * WK + kb + kk], kjk_acc[kk]); kjk_acc[kk] = 0; }
+                        }
+                        if (!keep_jl) {
+#pragma unroll
+                            for (int cl = 0; cl < NFL; cl++) { lds_add(&sKjl[jA * WL + lbs + cl], kjl_acc[cl]); kjl_acc[cl] = 0; }
+                        }
+#endif
+                    }
+                }
+            }
+#endif  // CJR
+#endif  // TILE_1Q
+            STAMP(6);
+            __syncthreads();
+            STAMP(7);
+            int tid_f = tid;
+            asm volatile("" : "+v"(tid_f));
+#define tid tid_f
+            {
+            // ---- ket-dependent Fock sub-blocks of this tile pair: one coalesced pass of global f64 atomics each
+#if KARG_RELOAD
+            const KArgs AS4* kf = kargs();
+            const int nao = kf->nao;
+            const size_t nao2 = (size_t)nao * nao;
+            double* __restrict__ vj = kf->vj;
+            double* __restrict__ vk = kf->vk;
+#endif
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                if (!kval[ks]) continue;
+                const int k0 = k0s[ks], l0 = l0s[ks];
+#if DO_J
+                flush_tile(sJkl + ks * (WL * WK), vj + idm * nao2, nao, l0, k0, WL, WK, tid);
+#endif
+#if DO_K
+                double* __restrict__ K = vk + idm * nao2;
+                flush_tile(sKik + ks * (WI * WK), K, nao, i0, k0, WI, WK, tid);
+                flush_tile(sKil + ks * (WI * WL), K, nao, i0, l0, WI, WL, tid);
+                flush_tile(sKjk + ks * (WJ * WK), K, nao, j0, k0, WJ, WK, tid);
+                flush_tile(sKjl + ks * (WJ * WL), K, nao, j0, l0, WJ, WL, tid);
+#endif
+            }
+            }
+#undef tid
+            STAMP(8);
+        }
+#if DO_J
+        __syncthreads();
+        {
+#if KARG_RELOAD
+            const KArgs AS4* kf = kargs();
+            const int nao = kf->nao;
+            const size_t nao2 = (size_t)nao * nao;
+            double* __restrict__ vj = kf->vj;
+#endif
+            flush_tile(sJij, vj + idm * nao2, nao, j0, i0, WJ, WI, tid);   // J_ij: summed over the whole ket chunk
+        }
+#endif
+        STAMP(9);
+    }
+#if STAMPS
+    if (tid == 0 && counter) {
+        for (int k = 0; k < 14; k++) atomicAdd(counter - 1 - k, st_acc[k]);
+        atomicAdd(counter - 16, 1ull);
+    }
+#endif
+#if KARG_RELOAD
+    {
+        const KArgs AS4* ke = kargs();
+        unsigned long long* cnt = ke->counter;
+        if (tid == 0 && cnt && nq_done) atomicAdd(cnt + ke->tasks[row * 8 + 6], (unsigned long long)nq_done);
+    }
+#else
+    if (tid == 0 && counter && nq_done) atomicAdd(counter + tk[6], (unsigned long long)nq_done);   // per task row (slot 6)
+#endif
+}

@@ -14,7 +14,9 @@ from functools import wraps
 from types import MethodType
 from typing import Any, Dict, Optional
 
-__all__ = ["apply", "reset", "get_default_config"]
+from . import parallel  # noqa: F401  (multi-GPU driver/worker protocol; imports nothing heavy)
+
+__all__ = ["apply", "reset", "get_default_config", "parallel"]
 
 
 def get_default_config() -> Dict[str, Any]:
@@ -22,6 +24,9 @@ def get_default_config() -> Dict[str, Any]:
     return {
         "jk": {"cutoff_fp32": None, "cutoff_fp64": None},   # None -> obj.direct_scf_tol
         "dft": {"cutoff_fp32": 1e-13, "cutoff_fp64": 1e-6},
+        # True: share the work over the ranks of the initialised torch.distributed group (joltqc_amd/pyscf/parallel.py);
+        # not in the reference, which drives one device
+        "parallel": False,
     }
 
 
@@ -92,14 +97,26 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
     basis_layout_jk = BasisLayout.from_mol(obj.mol, alignment=tile_width)
     obj._jqc_basis_layout = basis_layout_jk
     numpy_boundary = not is_device_obj
+    obj._jqc_numpy_boundary = numpy_boundary
+    shard = None
+    if config.get("parallel"):
+        from . import parallel as _par
+        rank, nranks = _par.world()
+        if nranks > 1:
+            shard = (rank, nranks)
+            obj._jqc_parallel = {}
 
 
     if hasattr(obj, "istype") and not obj.istype("DFRHF") and not obj.istype("DFRKS"):
-        def _mk(gen):
-            f = gen(basis_layout_jk, cutoff_fp32=jk_cutoff_fp32, cutoff_fp64=jk_cutoff_fp64)
-            return f
         if hasattr(obj, "get_jk"):
-            get_jk = _jk.generate_jk_kernel(basis_layout_jk, cutoff_fp32=jk_cutoff_fp32, cutoff_fp64=jk_cutoff_fp64)
+            get_jk = _jk.generate_jk_kernel(basis_layout_jk, cutoff_fp32=jk_cutoff_fp32, cutoff_fp64=jk_cutoff_fp64,
+                                            shard=shard)
+            if shard is not None:
+                # every rank evaluates its share of the quartets; rank 0 (the one that runs the SCF) announces each
+                # call and broadcasts D, the others mirror it from parallel.serve(obj)
+                obj._jqc_parallel[_par.OP_JK] = get_jk
+                if shard[0] == 0:
+                    get_jk = _par.drive_jk(get_jk)
             get_jk.return_numpy = numpy_boundary
             obj.get_jk = get_jk
             if hasattr(obj, "get_j"):
@@ -111,7 +128,7 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
 
     if _is(obj, "RKS"):                      # after the J/K closures: the RKS get_veff calls them
         from . import rks as _rks
-        _rks.patch(obj, BasisLayout.from_mol(obj.mol, alignment=1), dft_cutoff_fp32, dft_cutoff_fp64, numpy_boundary)
+        _rks.patch(obj, BasisLayout.from_mol(obj.mol, alignment=1), dft_cutoff_fp32, dft_cutoff_fp64, numpy_boundary, shard)
 
     obj._joltqc_applied = True
     if not hasattr(obj, "_jqc_original_reset") and hasattr(obj, "reset"):

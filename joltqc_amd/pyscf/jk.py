@@ -57,7 +57,9 @@ def generate_get_jk(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
 
 
 def generate_get_veff():
-    """RHF get_veff with incremental Fock build (reference jk.py:78-90)."""
+    """RHF get_veff with incremental Fock build (reference jk.py:78-90).  On a plain (CPU) PySCF object -- ``apply`` marks it
+    with ``_jqc_numpy_boundary`` -- the potential goes back as a NumPy array: PySCF adds it to ``h1e`` and contracts it with
+    the density in NumPy."""
     import torch
 
     def get_veff(mf, mol=None, dm=None, dm_last=None, vhf_last=None, hermi=1):
@@ -68,9 +70,11 @@ def generate_get_veff():
         incremental = dm_last is not None and not (np.isscalar(dm_last) and dm_last == 0) and getattr(mf, "direct_scf", True)
         d = as_t(dm) - as_t(dm_last) if incremental else as_t(dm)
         vj, vk = mf.get_jk(mol, d, hermi)
-        vhf = vj - 0.5 * vk
+        vhf = as_t(vj) - 0.5 * as_t(vk)
         if vhf_last is not None and not (np.isscalar(vhf_last) and vhf_last == 0):
             vhf = vhf + as_t(vhf_last)
+        if getattr(mf, "_jqc_numpy_boundary", False):
+            return vhf.cpu().numpy()
         return vhf
     return get_veff
 
@@ -396,6 +400,8 @@ def _shard_rows(per_class, rank, world):
     return mine
 
 
+_FIRST_USE_OK = set()       # kernel builds outside the verified manifest that passed their first-use cross-check (per process)
+
 KCHUNK_MAX = int(__import__('os').environ.get('JQC_KCHUNK_MAX', '16'))
 SPLIT_BELOW_WGS = int(__import__('os').environ.get('JQC_SPLIT_BELOW', '1024'))
 NSPLIT_MAX = int(__import__('os').environ.get('JQC_NSPLIT_MAX', '8'))
@@ -413,6 +419,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
     layout = basis_layout
     nbas = layout.nbasis
     nao = layout.nao
+    # the kernels index nbas x nbas tables and order shell pairs by ish * nbas + jsh in 32-bit integers
+    assert nbas <= 46340, "more than 46340 (padded) shells are not supported by the J/K kernels"
     from ..constants import tile_width
     # the tiled kernels need every (l, nprim) group padded to its tile width
     tiled_layout = all((layout.group_offset[g + 1] - layout.group_offset[g]) % tile_width(int(layout.group_key[g, 0])) == 0
@@ -465,6 +473,80 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
         counter_bufs = []
         tile_counts = None
         INF = 3.0e38
+
+        def run_queue(want, vj_q, vk_q, cut32, cut64, use_fp32, shard_q, record):
+            """Screening launch + one launch per class of the queue-driven one-quartet-per-lane kernels (jk_1q1t.hip) for the
+            classes ``want`` selects, accumulating into vj_q / vk_q."""
+            nonlocal n_launch
+            if om not in state["pairs"]:
+                state["pairs"][om] = _PairTables(layout, om)
+            pt = state["pairs"][om]
+            plans = build_screen_plan(layout, pt, cut32, log_max_dm, QUEUE_DEPTH, want, shard_q)
+            qsize = max((p["total"] for p in plans), default=0)
+            if plans and (state["queue"] is None or state["queue"].numel() < qsize * 4):
+                state["queue"] = torch.empty(max(qsize, 1) * 4, dtype=torch.int16, device=dev)
+            queue = state["queue"]
+            for p in plans:
+                ncls = len(p["classes"])
+                tasks_d = torch.from_numpy(p["tasks"]).to(dev)
+                region_d = torch.from_numpy(p["region"]).to(dev)
+                counters = torch.zeros((ncls, 2), dtype=torch.int32, device=dev)
+                if record:
+                    counter_bufs.append((counters, p))
+                _lib.check(L.jqc_screen_jk_tasks(tasks_d.data_ptr(), p["tasks"].shape[0], p["nblocks"], pt.sh.data_ptr(),
+                                                 pt.q.data_ptr(), log_dm_cond.data_ptr(), nbas, int(with_j), int(with_k),
+                                                 cut32, cut64, log_max_dm, queue.data_ptr(),
+                                                 region_d.data_ptr(), counters.data_ptr(), stream))
+                n_launch += 1
+                for n, ang in enumerate(p["classes"]):
+                    beg, end = int(p["region"][n, 0]), int(p["region"][n, 1])
+                    h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=_lib.ALGO_1Q1T)
+                    _lib.check(L.jqc_jk_launch(h64, nao, b64.data_ptr(), dms.data_ptr(), vj_q, vk_q, om,
+                                               queue.data_ptr() + beg * 8, counters.data_ptr() + (2 * n) * 4,
+                                               end - beg, 1, n_dm, stream))
+                    n_launch += 1
+                    if use_fp32:
+                        h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True,
+                                                    algo=_lib.ALGO_1Q1T)
+                        _lib.check(L.jqc_jk_launch(h32, nao, b32.data_ptr(), dms_fp32.data_ptr(), vj_q, vk_q,
+                                                   om, queue.data_ptr() + (end - 1) * 8,
+                                                   counters.data_ptr() + (2 * n + 1) * 4, end - beg, -1, n_dm, stream))
+                        n_launch += 1
+            return len(plans)
+
+        def tile_launch(h, fp32_kernel, vj_x, vk_x, lo, hi, cnt, sp_, tab_p, ntab, nblk, idx_p):
+            tt = state["tiles"][om]
+            bas, dmat = (b32, dms_fp32) if fp32_kernel else (b64, dms)
+            ptab = tt.pair_tab32() if fp32_kernel else tt.pair_tab
+            _lib.check(L.jqc_jk_tile_launch(h, nao, bas.data_ptr(), dmat.data_ptr(), vj_x, vk_x, om, tab_p, ntab, nblk,
+                                            tt.sh.data_ptr(), tt.q.data_ptr(), tt.q_dev.data_ptr(), log_dm_cond.data_ptr(),
+                                            nbas, lo, hi, log_max_dm, n_dm, cnt, idx_p, tt.ao.data_ptr(),
+                                            tt.pp_off.data_ptr(), ptab.data_ptr(), sp_))
+
+        def first_use_check(ang, algo_req, fp32_kernel, h, bucket):
+            """A tile-kernel build that is not in the verified manifest (joltqc_amd/data/verified_kernels.json: another
+            variant, edited sources, another compiler) is run once against the independent one-quartet-per-lane kernel on
+            this call's own inputs (whole class, unsharded); a build that disagrees raises instead of contributing to J/K."""
+            built = _router.resolved_algo(ang, with_j, with_k, lr, fp32_kernel, algo_req)
+            key = _router.kernel_key(ang, with_j, with_k, lr, fp32_kernel, built)
+            if key in _FIRST_USE_OK or _router.is_verified(ang, with_j, with_k, lr, fp32_kernel, built):
+                return
+            tab, nblk, _, index = build_tile_plan(layout, state["tiles"][om], log_cutoff_fp32, bucket,
+                                                  lambda a: tuple(a) == tuple(ang), None)[tuple(ang)]
+            tab_d, index_d = torch.from_numpy(tab).to(dev), torch.from_numpy(index).to(dev)
+            scratch = torch.zeros((2,) + tuple(fock.shape), dtype=torch.float64, device=dev)
+            pj = lambda m: scratch[m, 0].data_ptr() if with_j else None
+            pk = lambda m: scratch[m, -1].data_ptr() if with_k else None
+            tile_launch(h, fp32_kernel, pj(0), pk(0), log_cutoff_fp32, INF, None, stream, tab_d.data_ptr(), tab.shape[0], nblk,
+                        index_d.data_ptr())
+            run_queue(lambda a: tuple(a) == tuple(ang), pj(1), pk(1), log_cutoff_fp32, log_cutoff_fp32, False, None, False)
+            ref = float(scratch[1].abs().max().item())
+            err = float((scratch[0] - scratch[1]).abs().max().item())
+            tol = (2e-4 if fp32_kernel else 1e-9) * max(ref, 1e-300)
+            if not err <= tol:
+                raise RuntimeError(f"J/K kernel build {key} disagrees with the one-quartet-per-lane reference kernel on its "
+                                   f"first use (max |diff| {err:.3e}, largest element {ref:.3e}): the build is rejected")
+            _FIRST_USE_OK.add(key)
 
         # ---------------- tiled kernels: no queue, one launch per angular class, classes spread over streams
         if tiled_layout:
@@ -521,8 +603,10 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     idx_p = entry["index_d"].data_ptr() + entry["index_off"][ang] * 4
                     sid = side[n % len(side)]
                     sp = sid.cuda_stream
-                    h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False,
-                                                algo=_router.select_algo(ang, small=nblk < TARGET_WGS))
+                    algo64 = _router.select_algo(ang, small=nblk < TARGET_WGS)
+                    h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=algo64)
+                    geo = (tabs_d.data_ptr() + row * 32, tab.shape[0], nblk, idx_p)
+                    first_use_check(ang, algo64, False, h64, bucket)
                     probing = state["probe"] is not None and (state["probe"] == "all" or tuple(state["probe"]) == tuple(ang))
                     if probing:
                         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -532,22 +616,15 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     # elsewhere the fp64 kernel takes both windows in ONE launch (more accurate and, on this chip, faster:
                     # two launches stage and screen every tile pair twice)
                     split = mixed and (fp32_only or _router.fp32_pays(ang))
-                    _lib.check(L.jqc_jk_tile_launch(h64, nao, b64.data_ptr(), dms.data_ptr(), vj_p, vk_p, om,
-                                                    tabs_d.data_ptr() + row * 32, tab.shape[0], nblk, tt.sh.data_ptr(),
-                                                    tt.q.data_ptr(), tt.q_dev.data_ptr(), log_dm_cond.data_ptr(), nbas,
-                                                    log_cutoff_fp64 if split else log_cutoff_fp32, INF, log_max_dm, n_dm,
-                                                    tile_counts[0].data_ptr(), idx_p, tt.ao.data_ptr(), tt.pp_off.data_ptr(),
-                                                    tt.pair_tab.data_ptr(), sp))
+                    tile_launch(h64, False, vj_p, vk_p, log_cutoff_fp64 if split else log_cutoff_fp32, INF,
+                                tile_counts[0].data_ptr(), sp, *geo)
                     n_launch += 1
                     if split:
-                        h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True,
-                                                    algo=_router.select_algo(ang, True))
-                        _lib.check(L.jqc_jk_tile_launch(h32, nao, b32.data_ptr(), dms_fp32.data_ptr(), vj_p, vk_p, om,
-                                                        tabs_d.data_ptr() + row * 32, tab.shape[0], nblk,
-                                                        tt.sh.data_ptr(), tt.q.data_ptr(), tt.q_dev.data_ptr(),
-                                                        log_dm_cond.data_ptr(), nbas, log_cutoff_fp32, log_cutoff_fp64,
-                                                        log_max_dm, n_dm, tile_counts[1].data_ptr(), idx_p, tt.ao.data_ptr(), tt.pp_off.data_ptr(),
-                                                        tt.pair_tab32().data_ptr(), sp))
+                        algo32 = _router.select_algo(ang, True)
+                        h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True, algo=algo32)
+
+                        first_use_check(ang, algo32, True, h32, bucket)
+                        tile_launch(h32, True, vj_p, vk_p, log_cutoff_fp32, log_cutoff_fp64, tile_counts[1].data_ptr(), sp, *geo)
                         n_launch += 1
                     if probing:
                         ev1.record(sid)
@@ -566,41 +643,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
             not is_tile((int(a), int(b), int(c), int(d)))
             for a in set(layout.angs) for b in set(layout.angs) for c in set(layout.angs) for d in set(layout.angs)
             if a >= b and a >= c and c >= d)
-        plans = []
         if need_queue:
-            if om not in state["pairs"]:
-                state["pairs"][om] = _PairTables(layout, om)
-            pt = state["pairs"][om]
-            plans = build_screen_plan(layout, pt, log_cutoff_fp32, log_max_dm, QUEUE_DEPTH, want_q, shard)
-        qsize = max((p["total"] for p in plans), default=0)
-        if plans and (state["queue"] is None or state["queue"].numel() < qsize * 4):
-            state["queue"] = torch.empty(max(qsize, 1) * 4, dtype=torch.int16, device=dev)
-        queue = state["queue"]
-        for p in plans:
-            ncls = len(p["classes"])
-            tasks_d = torch.from_numpy(p["tasks"]).to(dev)
-            region_d = torch.from_numpy(p["region"]).to(dev)
-            counters = torch.zeros((ncls, 2), dtype=torch.int32, device=dev)
-            counter_bufs.append((counters, p))
-            _lib.check(L.jqc_screen_jk_tasks(tasks_d.data_ptr(), p["tasks"].shape[0], p["nblocks"], pt.sh.data_ptr(),
-                                             pt.q.data_ptr(), log_dm_cond.data_ptr(), nbas, int(with_j), int(with_k),
-                                             log_cutoff_fp32, log_cutoff_fp64, log_max_dm, queue.data_ptr(),
-                                             region_d.data_ptr(), counters.data_ptr(), stream))
-            n_launch += 1
-            for n, ang in enumerate(p["classes"]):
-                beg, end = int(p["region"][n, 0]), int(p["region"][n, 1])
-                h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=_lib.ALGO_1Q1T)
-                _lib.check(L.jqc_jk_launch(h64, nao, b64.data_ptr(), dms.data_ptr(), vj_p, vk_p, om,
-                                           queue.data_ptr() + beg * 8, counters.data_ptr() + (2 * n) * 4,
-                                           end - beg, 1, n_dm, stream))
-                n_launch += 1
-                if mixed:
-                    h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True,
-                                                algo=_lib.ALGO_1Q1T)
-                    _lib.check(L.jqc_jk_launch(h32, nao, b32.data_ptr(), dms_fp32.data_ptr(), vj_p, vk_p,
-                                               om, queue.data_ptr() + (end - 1) * 8,
-                                               counters.data_ptr() + (2 * n + 1) * 4, end - beg, -1, n_dm, stream))
-                    n_launch += 1
+            run_queue(want_q, vj_p, vk_p, log_cutoff_fp32, log_cutoff_fp64, mixed, shard, True)
 
         if shard is not None and shard[1] > 1:
             import torch.distributed as dist
@@ -631,7 +675,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
 
         st = state["stats"]
         st["launches"] = n_launch
-        st["chunks"] = len(plans)
+        st["chunks"] = len(counter_bufs)
         st["counter_bufs"] = counter_bufs          # read lazily by quartet_counts()
         st["tile_counts"] = tile_counts
         st["host_seconds"] = time.perf_counter() - t_start

@@ -46,14 +46,17 @@ class _GridCache:
     def coords(self, grids, dev):
         import torch
         c = grids.coords
-        key = (id(c), tuple(c.shape))
-        if self.key != key:
+        # the keyed array itself is kept (an id() can be reused by a new array once the old one is collected); a grid
+        # whose coords were replaced -- or whose generation counter (bumped by build_grids) changed -- is re-staged
+        key = (c, tuple(c.shape), getattr(grids, "_jqc_generation", 0))
+        if self.key is None or self.key[0] is not c or self.key[1:] != key[1:]:
             ct = _t(c, dev)
             n = ct.shape[0]
             npad = (-n) % NG
             if npad:
                 ct = torch.cat([ct, ct[-1:].expand(npad, 3)], dim=0)
             self.key = key
+            self.generation = getattr(self, "generation", 0) + 1     # incremental caches keyed on a grid check this
             self.ngrids = n
             self.ngrids_pad = n + npad
             self.soa = ct.T.contiguous()
@@ -98,11 +101,14 @@ def _batches(nrow_h, ncomp):
         b0 = b1
 
 
-def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
+def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard=None):
+    """``shard=(rank, world_size)``: this process evaluates a contiguous range of the 256-point grid blocks (cut by the
+    blocks' AO-pair counts) and the partial ``rho`` / ``vxcmat`` are summed over ranks with one all-reduce each."""
     import torch
     layout = basis_layout
     nao = layout.nao
-    cache = {"dm_prev": 0, "rho_prev": 0, "wv_prev": 0, "vxcmat_prev": 0}
+    rank, nranks = shard if shard is not None else (0, 1)
+    cache = {"dm_prev": 0, "rho_prev": 0, "wv_prev": 0, "vxcmat_prev": 0, "grid": None}
     gcache = _GridCache()
     state = {"ws": None, "stats": {}}
     log_ao_cutoff = math.log(min(ao_cutoff, cutoff_fp32))
@@ -121,7 +127,13 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
         basis = layout.basis_data_fp64["packed"]
         stream = _lib.stream_ptr()
         rows_total = 0
-        for blk0, nblk, base, rows in _batches(nrow_h, ncomp_ao):
+        b_lo, b_hi = 0, len(nrow_h)
+        if nranks > 1:
+            from .parallel import split_blocks
+            b_lo, b_hi = split_blocks(nrow_h.astype(np.float64) ** 2 + 64.0 * nrow_h + 1.0, rank, nranks)
+        state["stats"]["block_range"] = (b_lo, b_hi)
+        for blk0, nblk, base, rows in _batches(nrow_h[b_lo:b_hi], ncomp_ao):
+            blk0 += b_lo
             ws = _workspace(dev, rows, ncomp_ao)
             base_d = torch.from_numpy(base).to(dev)
             ao_idx = torch.empty(rows, dtype=torch.int32, device=dev)
@@ -152,8 +164,10 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
             _lib.check(L.jqc_dft_rho(blk0, nblk, gcache.ngrids_pad, nrow.data_ptr(), base_d.data_ptr(), comp_stride,
                                      ws.data_ptr(), ao_idx.data_ptr(), d.data_ptr(), nao, ndim, rho.data_ptr(), stream))
         _run(grids, 1 if ndim == 1 else 4, log_ao_cutoff - log_dm, body)
-        out = rho[:, :gcache.ngrids]
-        return out[0] if False else out
+        if nranks > 1:
+            import torch.distributed as dist
+            dist.all_reduce(rho)                  # every rank filled its own block range, zeros elsewhere
+        return rho[:, :gcache.ngrids]
 
     def vxc_fun(mol, grids, xctype, wv):
         """V_xc matrix in the molecule's AO basis from weighted potential wv[ndim, ngrids]
@@ -176,25 +190,49 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
             _lib.check(L.jqc_dft_vxc(blk0, nblk, gcache.ngrids_pad, nrow.data_ptr(), base_d.data_ptr(), comp_stride,
                                      ws.data_ptr(), ao_idx.data_ptr(), w.data_ptr(), ndim, nao, vmat.data_ptr(), stream))
         _run(grids, 1 if ndim == 1 else 4, log_ao_cutoff - log_wv_max, body)
+        if nranks > 1:
+            import torch.distributed as dist
+            dist.all_reduce(vmat)                 # the one collective of nr_rks: sum of the ranks' block ranges
         return layout.dm_to_mol(vmat + vmat.T)          # the kernel accumulates T = phi X^T only (reference epilogue A + A^T, :654-655)
+
+    def _eval_xc(ni, xc_code, rho, xctype, dev):
+        """``ni.eval_xc_eff`` (libxc, third party) on the caller's side of the boundary: a plain PySCF NumInt takes and
+        returns NumPy arrays, a device-resident one (GPU4PySCF-like, ``_jqc_numpy_boundary`` False) device arrays."""
+        if getattr(ni, "_jqc_numpy_boundary", True):
+            exc, vxc = ni.eval_xc_eff(xc_code, rho.cpu().numpy(), deriv=1, xctype=xctype)[:2]
+        else:
+            exc, vxc = ni.eval_xc_eff(xc_code, rho, deriv=1, xctype=xctype)[:2]
+        return _t(exc, dev).reshape(-1), _t(vxc, dev).reshape(rho.shape[0], -1)
 
     def rks_fun(ni, mol, grids, xc_code, dm):
         """Incremental nr_rks (reference rks.py:308-364): returns (nelec, excsum, vxcmat)."""
         dev = _lib.require_gpu()
         xctype = ni._xc_type(xc_code) if hasattr(ni, "_xc_type") else _xc_type(xc_code)
+        gcache.coords(grids, dev)
+        if cache["grid"] != gcache.generation:      # another grid (new geometry, rebuilt grid): the increments restart
+            cache.update(dm_prev=0, rho_prev=0, wv_prev=0, vxcmat_prev=0, grid=gcache.generation)
         weights = _t(grids.weights, dev)
         dm_t = _t(dm, dev)
-        rho = cache["rho_prev"] + rho_fun(mol, grids, xctype, dm_t - cache["dm_prev"])
-        exc, vxc = ni.eval_xc_eff(xc_code, rho, deriv=1, xctype=xctype)[:2]
-        exc, vxc = _t(exc, dev), _t(vxc, dev)
-        exc = exc.reshape(-1)
+        rho = cache["rho_prev"] + rho_k(mol, grids, xctype, dm_t - cache["dm_prev"])
+        exc, vxc = _eval_xc(ni, xc_code, rho, xctype, dev)
         den = rho[0] * weights
         nelec = float(den.sum())
         excsum = float((den * exc).sum())
-        wv = vxc.reshape(rho.shape[0], -1) * weights
-        vxcmat = cache["vxcmat_prev"] + vxc_fun(mol, grids, xctype, wv - cache["wv_prev"])
+        wv = vxc * weights
+        vxcmat = cache["vxcmat_prev"] + vxc_k(mol, grids, xctype, wv - cache["wv_prev"])
         cache.update(dm_prev=dm_t.clone(), rho_prev=rho, wv_prev=wv, vxcmat_prev=vxcmat.clone())
+        if getattr(ni, "_jqc_numpy_boundary", False):
+            return nelec, excsum, vxcmat.cpu().numpy()
         return nelec, excsum, vxcmat
+
+    # rank 0 of a multi-GPU run announces every grid call to the workers (parallel.drive_grid); set by ``patch``
+    rho_k, vxc_k = rho_fun, vxc_fun
+
+    def set_drivers(rho_d, vxc_d):
+        nonlocal rho_k, vxc_k
+        rho_k, vxc_k = rho_d, vxc_d
+    rks_fun.set_drivers = set_drivers
+    rks_fun.gcache = gcache
 
     rho_fun.stats = state["stats"]
     vxc_fun.stats = state["stats"]
@@ -206,25 +244,52 @@ def _xc_type(xc_code):
     return libxc.xc_type(xc_code)
 
 
-def generate_get_rho(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
-    _, rho_fun, _ = generate_rks_kernel(basis_layout, cutoff_fp64, cutoff_fp32)
+def generate_get_rho(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, kernels=None):
+    _, rho_fun, _ = kernels or generate_rks_kernel(basis_layout, cutoff_fp64, cutoff_fp32)
 
     def get_rho(mol, dm, grids, *args, **kwargs):
         return rho_fun(mol, grids, "LDA", dm)[0]
     return get_rho
 
 
-def generate_nr_rks(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
-    rks_fun, _, _ = generate_rks_kernel(basis_layout, cutoff_fp64, cutoff_fp32)
+def generate_nr_rks(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, kernels=None):
+    rks_fun, _, _ = kernels or generate_rks_kernel(basis_layout, cutoff_fp64, cutoff_fp32)
     return rks_fun
 
 
 # --------------------------------------------------------------------------------------------- VV10
-def vv10nlc(rho, coords, vvrho, vvweight, vvcoords, nlc_pars, dtype=np.float32):
-    """VV10 non-local correlation: exc[ngrids], vxc[2, ngrids] (reference jqc/backend/rks.py:542-715)."""
+def vv10_sums(outer, inner, fp32=True, shard=None):
+    """The O(N_outer x N_inner) part of VV10: F, U, W sums of ``vv10_kernel`` (reference dft/vv10.cu:29-118).
+    ``outer`` = [x, y, z, W0, K][n_o] and ``inner`` = [x, y, z, W0p, Kp, RpW][n_i] device matrices, both padded to 256.
+    ``shard=(rank, world)``: this process takes a contiguous range of the outer points; ONE all-reduce sums the stacked
+    [F; U; W] (zeros outside the own range)."""
+    import torch
+    dev = outer.device
+    L = _lib.lib()
+    no_pad, ni_pad = int(outer.shape[1]), int(inner.shape[1])
+    out = torch.zeros((3, no_pad), dtype=torch.float64, device=dev)
+    rank, nranks = shard if shard is not None else (0, 1)
+    nblk = no_pad // NG
+    b0, b1 = (nblk * rank) // nranks, (nblk * (rank + 1)) // nranks
+    if b1 > b0 and ni_pad:
+        o = outer[:, b0 * NG:b1 * NG].contiguous()
+        res = torch.empty((3, (b1 - b0) * NG), dtype=torch.float64, device=dev)
+        _lib.check(L.jqc_vv10(res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), inner[:3].contiguous().data_ptr(),
+                              o[:3].contiguous().data_ptr(), inner[3].data_ptr(), o[3].contiguous().data_ptr(),
+                              o[4].contiguous().data_ptr(), inner[4].data_ptr(), inner[5].data_ptr(), ni_pad,
+                              (b1 - b0) * NG, int(bool(fp32)), _lib.stream_ptr()))
+        out[:, b0 * NG:b1 * NG] = res
+    if nranks > 1:
+        import torch.distributed as dist
+        dist.all_reduce(out)
+    return out
+
+
+def vv10nlc(rho, coords, vvrho, vvweight, vvcoords, nlc_pars, dtype=np.float32, sums=vv10_sums):
+    """VV10 non-local correlation: exc[ngrids], vxc[2, ngrids] (reference jqc/backend/rks.py:542-715).
+    ``sums``: the kernel call (rank 0 of a multi-GPU run passes the broadcasting form, parallel.drive_vv10)."""
     import torch
     dev = _lib.require_gpu()
-    L = _lib.lib()
     rho, vvrho = _t(rho, dev), _t(vvrho, dev)
     coords, vvcoords, vvweight = _t(coords, dev), _t(vvcoords, dev), _t(vvweight, dev)
     thresh = 1e-10
@@ -250,18 +315,14 @@ def vv10nlc(rho, coords, vvrho, vvweight, vvcoords, nlc_pars, dtype=np.float32):
         return out
     n_o, n_i = int(dens.numel()), int(idens.numel())
     no_pad, ni_pad = n_o + (-n_o) % NG, n_i + (-n_i) % NG
-    c_o = pad(coords[m], no_pad, 0.0).T.contiguous()
-    c_i = pad(vvcoords[mi], ni_pad, 1.0e4).T.contiguous()      # padding points far away with zero weight
-    W0_, K_ = pad(W0, no_pad, 1.0), pad(K, no_pad, 1.0)
-    W0p_, Kp_, RpW_ = pad(W0p, ni_pad, 1.0), pad(Kp, ni_pad, 1.0), pad(RpW, ni_pad, 0.0)
-    F = torch.empty(no_pad, dtype=torch.float64, device=dev)
-    U = torch.empty_like(F)
-    W = torch.empty_like(F)
+    outer = torch.cat([pad(coords[m], no_pad, 0.0).T, pad(W0, no_pad, 1.0)[None], pad(K, no_pad, 1.0)[None]]).contiguous()
+    # padding points of the inner grid: far away, zero weight
+    inner = torch.cat([pad(vvcoords[mi], ni_pad, 1.0e4).T, pad(W0p, ni_pad, 1.0)[None], pad(Kp, ni_pad, 1.0)[None],
+                       pad(RpW, ni_pad, 0.0)[None]]).contiguous()
     if no_pad and ni_pad:
-        _lib.check(L.jqc_vv10(F.data_ptr(), U.data_ptr(), W.data_ptr(), c_i.data_ptr(), c_o.data_ptr(), W0p_.data_ptr(),
-                              W0_.data_ptr(), K_.data_ptr(), Kp_.data_ptr(), RpW_.data_ptr(), ni_pad, no_pad,
-                              int(np.dtype(dtype) == np.float32), _lib.stream_ptr()))
-    F, U, W = F[:n_o], U[:n_o], W[:n_o]
+        F, U, W = sums(outer, inner, np.dtype(dtype) == np.float32)[:, :n_o]
+    else:
+        F = U = W = torch.zeros(n_o, dtype=torch.float64, device=dev)
     dW0dR = (0.5 * Pi43 * dens - 2.0 * W0tmp) / W0
     dW0dG = W0tmp * dens / (g2 * W0)
     n = rho.shape[1]
@@ -283,28 +344,37 @@ def transform_vxc_gga(rho, vxc):
     return out
 
 
-def generate_nr_nlc_vxc(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
+def generate_nr_nlc_vxc(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard=None):
     """Incremental nr_nlc_vxc (reference rks.py:661-714)."""
-    _, rho_fun, vxc_fun = generate_rks_kernel(basis_layout, cutoff_fp64, cutoff_fp32)
-    cache = {"dm_prev": 0, "rho_prev": 0, "wv_prev": 0, "vmat_prev": 0}
+    _, rho_fun, vxc_fun = generate_rks_kernel(basis_layout, cutoff_fp64, cutoff_fp32, shard)
+    cache = {"dm_prev": 0, "rho_prev": 0, "wv_prev": 0, "vmat_prev": 0, "grid": None}
+    calls = {"rho": rho_fun, "vxc": vxc_fun, "sums": lambda o, i, f: vv10_sums(o, i, f, shard)}
+    gc = _GridCache()
 
     def nr_nlc_vxc(ni, mol, grids, xc_code, dms):
         dev = _lib.require_gpu()
+        gc.coords(grids, dev)
+        if cache["grid"] != gc.generation:
+            cache.update(dm_prev=0, rho_prev=0, wv_prev=0, vmat_prev=0, grid=gc.generation)
         dm_t = _t(dms, dev)
-        rho = cache["rho_prev"] + rho_fun(mol, grids, "GGA", dm_t - cache["dm_prev"])
+        rho = cache["rho_prev"] + calls["rho"](mol, grids, "GGA", dm_t - cache["dm_prev"])
         weights, coords = _t(grids.weights, dev), _t(grids.coords, dev)
         exc, vxc = 0, 0
         for nlc_pars, fac in ni.nlc_coeff(xc_code):
-            e, v = vv10nlc(rho, coords, rho, weights, coords, nlc_pars)
+            e, v = vv10nlc(rho, coords, rho, weights, coords, nlc_pars, sums=calls["sums"])
             exc = exc + e * fac
             vxc = vxc + v * fac
         den = rho[0] * weights
         nelec = float(den.sum())
         excsum = float((den * exc).sum())
         wv = transform_vxc_gga(rho, vxc) * weights
-        vmat = cache["vmat_prev"] + vxc_fun(mol, grids, "GGA", wv - cache["wv_prev"])
+        vmat = cache["vmat_prev"] + calls["vxc"](mol, grids, "GGA", wv - cache["wv_prev"])
         cache.update(dm_prev=dm_t.clone(), rho_prev=rho, wv_prev=wv, vmat_prev=vmat.clone())
+        if getattr(ni, "_jqc_numpy_boundary", False):
+            return nelec, excsum, vmat.cpu().numpy()
         return nelec, excsum, vmat
+    nr_nlc_vxc.calls = calls
+    nr_nlc_vxc.kernels = (rho_fun, vxc_fun)
     return nr_nlc_vxc
 
 
@@ -338,6 +408,7 @@ def build_grids(grids, mol=None, with_non0tab=False, sort_grids=True, **kwargs):
         coords = np.vstack([coords, np.repeat(coords[-1:], npad, axis=0)])
         weights = np.concatenate([weights, np.zeros(npad)])
     grids.coords, grids.weights = coords, weights
+    grids._jqc_generation = getattr(grids, "_jqc_generation", 0) + 1
     return grids
 
 
@@ -369,8 +440,12 @@ def generate_get_veff():
         dev = _lib.require_gpu()
         if hasattr(ks, "initialize_grids"):
             ks.initialize_grids(mol, dm)
-        elif getattr(ks.grids, "coords", None) is None:
-            ks.grids.build()
+        else:                                       # plain PySCF: rks.get_veff builds the grids on first use
+            if getattr(ks.grids, "coords", None) is None:
+                ks.grids.build(with_non0tab=False)
+            if (hasattr(ks, "do_nlc") and ks.do_nlc() and getattr(ks, "nlcgrids", None) is not None
+                    and getattr(ks.nlcgrids, "coords", None) is None):
+                ks.nlcgrids.build(with_non0tab=False)
         dm_t = _t(dm, dev)
         ground_state = dm_t.ndim == 2
         ni = ks._numint
@@ -378,11 +453,12 @@ def generate_get_veff():
             n, exc, vxc = 0, 0, 0
         else:
             n, exc, vxc = ni.nr_rks(mol, ks.grids, ks.xc, dm_t)
+            vxc = _t(vxc, dev)                    # (NumPy when the object is a plain CPU one)
             if hasattr(ks, "do_nlc") and ks.do_nlc():
                 xc = ks.xc if ni.libxc.is_nlc(ks.xc) else ks.nlc
                 n, enlc, vnlc = ni.nr_nlc_vxc(mol, ks.nlcgrids, xc, dm_t)
                 exc += enlc
-                vxc = vxc + vnlc
+                vxc = vxc + _t(vnlc, dev)
         is_hybrid = ni.libxc.is_hybrid_xc(ks.xc) if hasattr(ni, "libxc") else False
         incremental = getattr(ks, "_eri", None) is None and getattr(ks, "direct_scf", True)
         if not is_hybrid:
@@ -414,16 +490,48 @@ def generate_get_veff():
     return get_veff
 
 
-def patch(obj, basis_layout, cutoff_fp32, cutoff_fp64, numpy_boundary):
-    """Install the grid-path closures on an RKS object (reference __init__.py:191-206)."""
+def patch(obj, basis_layout, cutoff_fp32, cutoff_fp64, numpy_boundary, shard=None):
+    """Install the grid-path closures on an RKS object (reference __init__.py:191-206).  ``shard=(rank, world)``: the grid
+    blocks (and the VV10 outer points) are shared by the ranks; rank 0's closures announce every call to the workers
+    (parallel.serve on the other ranks, handlers in ``obj._jqc_parallel``)."""
     from types import MethodType
+    from . import parallel as par
     ni = obj._numint
-    ni.get_rho = generate_get_rho(basis_layout, cutoff_fp32=cutoff_fp32, cutoff_fp64=cutoff_fp64)
-    ni.nr_rks = MethodType(generate_nr_rks(basis_layout, cutoff_fp32=cutoff_fp32, cutoff_fp64=cutoff_fp64), ni)
-    ni.nr_nlc_vxc = MethodType(generate_nr_nlc_vxc(basis_layout, cutoff_fp32=cutoff_fp32, cutoff_fp64=cutoff_fp64), ni)
-    if hasattr(obj, "grids") and hasattr(obj.grids, "build") and not hasattr(obj.grids, "_jqc_original_build"):
-        obj.grids._jqc_original_build = obj.grids.build
-        obj.grids.build = MethodType(build_grids, obj.grids)
+    kernels = generate_rks_kernel(basis_layout, cutoff_fp32=cutoff_fp32, cutoff_fp64=cutoff_fp64, shard=shard)
+    rks_fun, rho_fun, vxc_fun = kernels
+    nlc = generate_nr_nlc_vxc(basis_layout, cutoff_fp32=cutoff_fp32, cutoff_fp64=cutoff_fp64, shard=shard)
+    if shard is not None and shard[1] > 1:
+        handlers = getattr(obj, "_jqc_parallel", None)
+        handlers = {} if handlers is None else handlers
+        mol = obj.mol
+
+        def main_grid():
+            if getattr(obj.grids, "coords", None) is None:
+                obj.grids.build(with_non0tab=False)
+            return obj.grids
+
+        def nlc_grid():
+            if getattr(obj.nlcgrids, "coords", None) is None:
+                obj.nlcgrids.build(with_non0tab=False)
+            return obj.nlcgrids
+        handlers[par.OP_RHO] = {0: (rho_fun, mol, main_grid), 1: (nlc.kernels[0], mol, nlc_grid)}
+        handlers[par.OP_VXC] = {0: (vxc_fun, mol, main_grid), 1: (nlc.kernels[1], mol, nlc_grid)}
+        handlers[par.OP_VV10] = lambda o, i, f: vv10_sums(o, i, f, shard)
+        obj._jqc_parallel = handlers
+        if shard[0] == 0:
+            rho_d, vxc_d = par.drive_grid(rho_fun, par.OP_RHO, 0), par.drive_grid(vxc_fun, par.OP_VXC, 0)
+            rks_fun.set_drivers(rho_d, vxc_d)
+            kernels = (rks_fun, rho_d, vxc_d)
+            nlc.calls.update(rho=par.drive_grid(nlc.kernels[0], par.OP_RHO, 1), vxc=par.drive_grid(nlc.kernels[1], par.OP_VXC, 1),
+                             sums=par.drive_vv10(lambda o, i, f: vv10_sums(o, i, f, shard)))
+    ni.get_rho = generate_get_rho(basis_layout, kernels=kernels)
+    ni.nr_rks = MethodType(rks_fun, ni)
+    ni.nr_nlc_vxc = MethodType(nlc, ni)
+    ni._jqc_numpy_boundary = numpy_boundary
+    for g in {id(x): x for x in (getattr(obj, "grids", None), getattr(obj, "nlcgrids", None)) if x is not None}.values():
+        if hasattr(g, "build") and not hasattr(g, "_jqc_original_build"):
+            g._jqc_original_build = g.build
+            g.build = MethodType(build_grids, g)
     obj._jqc_numpy_boundary = numpy_boundary
     obj.get_veff = MethodType(generate_get_veff(), obj)
     return obj

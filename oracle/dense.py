@@ -23,7 +23,9 @@ def canonical_quartets(layout):
     return np.array(out, dtype=np.uint16).reshape(-1, 4)
 
 
-def get_jk(layout, dm, hermi=1, omega=None, with_j=True, with_k=True, quartets=None):
+def get_jk(layout, dm, hermi=1, omega=None, with_j=True, with_k=True, quartets=None, cutoff=None, dense_loop=False):
+    """``dense_loop``/``cutoff``: generate the canonical quartets inside the C loop (OpenMP over the host cores), optionally
+    dropping those whose Schwarz estimate is below ``cutoff`` -- for cases with 1e7..1e8 quartets (benzene/def2-TZVPP)."""
     dm = np.asarray(dm, dtype=np.float64)
     shape = dm.shape
     T = layout.transform_matrix()
@@ -31,8 +33,11 @@ def get_jk(layout, dm, hermi=1, omega=None, with_j=True, with_k=True, quartets=N
     dms = np.einsum("pi,nij,qj->npq", T, dms, T)
     if hermi == 0:
         dms = np.concatenate([dms, dms.transpose(0, 2, 1)])
-    q = canonical_quartets(layout) if quartets is None else quartets
-    vj, vk = O.jk_raw(layout.packed, dms, q, omega or 0.0, with_j, with_k)
+    if quartets is None and (dense_loop or cutoff is not None):
+        vj, vk, _ = O.jk_raw_dense(layout.packed, dms, layout.pad_id, omega or 0.0, with_j, with_k, cutoff)
+    else:
+        q = canonical_quartets(layout) if quartets is None else quartets
+        vj, vk = O.jk_raw(layout.packed, dms, q, omega or 0.0, with_j, with_k)
     n = dms.shape[0]
     res = []
     if with_j:

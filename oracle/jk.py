@@ -32,6 +32,11 @@ def lib():
         L.jqc_oracle_jk.argtypes = [ctypes.c_int, dp, ctypes.c_int, dp, dp, dp, ctypes.c_double,
                                     ctypes.POINTER(ctypes.c_uint16), ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.jqc_oracle_schwarz.argtypes = [dp, ctypes.c_int, ctypes.c_double, dp]
+        L.jqc_oracle_jk_mt.argtypes = L.jqc_oracle_jk.argtypes + [ctypes.c_int]
+        L.jqc_oracle_jk_dense.argtypes = [ctypes.c_int, dp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte), ctypes.c_int, dp, dp, dp,
+                                          ctypes.c_double, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int]
+        L.jqc_oracle_jk_dense.restype = ctypes.c_long
         from joltqc_amd.backend.rys import pack_tables  # data file only (numbers), no product code path
         _BLOB = np.array(pack_tables())
         L.jqc_oracle_set_rys(_BLOB.ctypes.data_as(dp))
@@ -61,8 +66,9 @@ def eri_block(basis, ish, jsh, ksh, lsh, omega=0.0):
     return out
 
 
-def jk_raw(basis, dm, quartets, omega=0.0, do_j=True, do_k=True):
-    """Raw (pre-epilogue) vj, vk for internal-order Cartesian density matrices dm[n_dm,nao,nao]."""
+def jk_raw(basis, dm, quartets, omega=0.0, do_j=True, do_k=True, nthreads=1):
+    """Raw (pre-epilogue) vj, vk for internal-order Cartesian density matrices dm[n_dm,nao,nao].
+    ``nthreads`` > 1: the quartet list is dealt to OpenMP threads (private accumulators, summed at the end)."""
     basis = np.ascontiguousarray(basis, dtype=np.float64)
     dm = np.ascontiguousarray(dm, dtype=np.float64)
     if dm.ndim == 2:
@@ -71,9 +77,34 @@ def jk_raw(basis, dm, quartets, omega=0.0, do_j=True, do_k=True):
     q = np.ascontiguousarray(quartets, dtype=np.uint16).reshape(-1, 4)
     vj = np.zeros_like(dm)
     vk = np.zeros_like(dm)
-    lib().jqc_oracle_jk(nao, _dp(basis), n_dm, _dp(dm), _dp(vj), _dp(vk), float(omega or 0.0),
-                        q.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), q.shape[0], int(do_j), int(do_k))
+    lib().jqc_oracle_jk_mt(nao, _dp(basis), n_dm, _dp(dm), _dp(vj), _dp(vk), float(omega or 0.0),
+                           q.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), q.shape[0], int(do_j), int(do_k), int(nthreads))
     return vj, vk
+
+
+def jk_raw_dense(basis, dm, skip, omega=0.0, do_j=True, do_k=True, cutoff=None, nthreads=None):
+    """Raw vj, vk over EVERY canonical quartet of the shells with ``skip[s] == False``, generated inside the C loop
+    (OpenMP).  ``cutoff``: drop quartets whose Schwarz estimate Q_ij Q_kl max|D| is below it (the checker's own,
+    much looser screening for big cases; None = no screening at all).  Returns (vj, vk, number of quartets)."""
+    basis = np.ascontiguousarray(basis, dtype=np.float64)
+    dm = np.ascontiguousarray(dm, dtype=np.float64)
+    if dm.ndim == 2:
+        dm = dm[None]
+    n_dm, nao, _ = dm.shape
+    nbas = basis.shape[0]
+    sk = np.ascontiguousarray(np.asarray(skip, dtype=np.uint8))
+    vj, vk = np.zeros_like(dm), np.zeros_like(dm)
+    lq = None
+    log_cut, log_dmax = -1e300, 0.0
+    if cutoff is not None:
+        lq = np.log(schwarz(basis, omega) + 1e-300)
+        log_cut = float(np.log(cutoff))
+        log_dmax = float(np.log(np.abs(dm).max() + 1e-300))
+    nt = int(nthreads or os.cpu_count() or 1)
+    n = lib().jqc_oracle_jk_dense(nao, _dp(basis), nbas, sk.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), n_dm, _dp(dm),
+                                  _dp(vj), _dp(vk), float(omega or 0.0), _dp(lq) if lq is not None else None, log_dmax,
+                                  log_cut, int(do_j), int(do_k), nt)
+    return vj, vk, int(n)
 
 
 def schwarz(basis, omega=0.0):

@@ -1,18 +1,31 @@
-"""Minimal RHF driver with the attribute surface ``apply`` patches.
+"""TEST SCAFFOLDING: minimal RHF / RKS drivers with the attribute surface ``joltqc_amd.pyscf.apply`` patches.
 
-Stand-in for ``pyscf.scf.RHF`` on images without PySCF (this one, and the GPU box): it owns the SCF
-loop, DIIS and the one-electron matrices handed to it, and calls ``self.get_veff`` /
-``self.get_jk`` exactly where PySCF does, so ``joltqc_amd.pyscf.apply(mf)`` patches it the same way
-it patches a PySCF object.  It computes no integrals itself: ``hcore`` and ``ovlp`` are supplied by
-the caller (PySCF's ``mf.get_hcore()`` / ``mf.get_ovlp()`` where PySCF exists; the test-suite's
-McMurchie-Davidson code otherwise).  Not part of the hot path.
+Stand-in for ``pyscf.scf.RHF`` / ``pyscf.dft.RKS`` on images without PySCF (this one, and the GPU box).  It behaves
+like a plain CPU PySCF object and is deliberately STRICT about it: everything it receives from the patched closures
+goes through ``numpy.asarray`` exactly where PySCF does its NumPy arithmetic (``h1e + vhf``, ``energy_elec``, libxc's
+``eval_xc_eff``), which raises ``TypeError`` on a CUDA tensor -- so a closure that leaks a device array across the
+boundary fails here the way it would under PySCF.  It owns the SCF loop and DIIS, calls ``self.get_veff`` /
+``self.get_jk`` where PySCF does, and computes no integrals itself: ``hcore`` and ``ovlp`` come from the caller (or
+from ``int1e``, a callback mol -> (hcore, ovlp), which ``reset(mol)`` uses after a geometry change).
 """
+import copy
+
 import numpy as np
 
 
+def _strict(x):
+    """What PySCF's NumPy code does with a potential: ``numpy.asarray`` (TypeError on a CUDA tensor)."""
+    if hasattr(x, "is_cuda") and x.is_cuda:
+        raise TypeError("a CUDA tensor crossed the NumPy boundary of a CPU PySCF-like object")
+    return np.asarray(x)
+
+
 class RHF:
-    def __init__(self, mol, hcore=None, ovlp=None):
+    def __init__(self, mol, hcore=None, ovlp=None, int1e=None):
         self.mol = mol
+        self._int1e = int1e
+        if hcore is None and int1e is not None:
+            hcore, ovlp = int1e(mol)
         self._hcore = hcore
         self._ovlp = ovlp
         self.direct_scf = True
@@ -45,9 +58,27 @@ class RHF:
         return vj - 0.5 * vk
 
     def reset(self, mol=None):
+        """pyscf.scf.hf.SCF.reset: new molecule, cached integrals dropped."""
         if mol is not None:
             self.mol = mol
+            if self._int1e is not None:
+                self._hcore, self._ovlp = self._int1e(mol)
+        self.mo_coeff = self.mo_energy = self.e_tot = None
+        self.converged = False
         return self
+
+    def as_scanner(self):
+        """pyscf.scf.hf.as_scanner: an object that, called with a molecule, resets itself to it and returns the energy."""
+        base = self.__class__
+
+        class Scanner(base):
+            def __init__(self, mf):
+                self.__dict__.update(copy.copy(mf.__dict__))
+
+            def __call__(self, mol, **kw):
+                self.reset(mol)
+                return self.kernel()
+        return Scanner(self)
 
     def make_rdm1(self, mo_coeff=None, nocc=None):
         c = self.mo_coeff if mo_coeff is None else mo_coeff
@@ -55,9 +86,7 @@ class RHF:
         return 2.0 * c[:, :nocc] @ c[:, :nocc].T
 
     # --- SCF loop -----------------------------------------------------------------------------
-    @staticmethod
-    def _np(x):
-        return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+    _np = staticmethod(_strict)
 
     def kernel(self, dm0=None):
         S, h = np.asarray(self._ovlp), np.asarray(self._hcore)
@@ -137,7 +166,8 @@ class SlaterNumInt:
         return "LDA"
 
     def eval_xc_eff(self, xc_code, rho, deriv=1, xctype="LDA"):
-        r = rho[0].clamp_min(0) if hasattr(rho, "clamp_min") else np.maximum(rho[0], 0)
+        rho = _strict(rho)                 # libxc's NumInt calls numpy.asarray on the density
+        r = np.maximum(rho[0] if rho.ndim == 2 else rho, 0)
         e = self.CX * r ** (1.0 / 3.0)
         return e.reshape(-1, 1), (4.0 / 3.0 * e).reshape(1, -1)
 
@@ -160,8 +190,8 @@ class RKS(RHF):
     """Minimal restricted Kohn-Sham driver with the attribute surface ``apply`` patches on an RKS object
     (``_numint``, ``grids``, ``xc``, ``get_j/get_k/get_jk``, ``get_veff`` returning a tagged potential)."""
 
-    def __init__(self, mol, hcore, ovlp, grids, xc="slater", numint=None):
-        super().__init__(mol, hcore, ovlp)
+    def __init__(self, mol, hcore, ovlp, grids, xc="slater", numint=None, int1e=None):
+        super().__init__(mol, hcore, ovlp, int1e)
         self.grids = grids
         self.nlcgrids = grids
         self.xc = xc
@@ -196,6 +226,7 @@ class RKS(RHF):
             veff = self.get_veff(self.mol, dm, dm_last=dm_last, vhf_last=v_last, hermi=1)
             dm_last, v_last = dm, veff
             F = h + self._np(veff)
+            _strict(veff.vj)
             e_tot = float(np.einsum("ij,ji->", dm, h)) + float(veff.ecoul) + float(veff.exc) + enuc
             err = X.T @ (F @ dm @ S - S @ dm @ F) @ X
             focks.append(F); errs.append(err)

@@ -143,7 +143,7 @@ def test_rhf_energy_h2o_tzvpp_through_apply(kats):
     import joltqc_amd.pyscf as jp
     from joltqc_amd.gto import mole
     from joltqc_amd.pyscf.basis import BasisLayout
-    from joltqc_amd.scf import RHF
+    from standin_scf import RHF
     from oracle import dense
     k = kats["h2o_def2tzvpp"]
     mol = mole.Mole(atom=k["atom"], basis="def2-tzvpp")
@@ -281,13 +281,15 @@ def test_two_ranks_share_the_quartets_and_allreduce_the_fock_matrix():
     assert min(res[0][3], res[1][3]) > 0.25 * n_all
 
 
-@pytest.mark.parametrize("mode", ["jk", "j", "k", "lr", "fp32"])
-def test_every_angular_class_against_the_oracle(mode):
+@pytest.mark.parametrize("mode", ["jk", "j", "k", "lr", "fp32", "k_lr", "fp32_lr", "jk_main", "k_lr_main"])
+def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     """All 140 angular classes s..g, CLASS BY CLASS: the kernel the scheme table selects for the class vs the CPU oracle
     restricted to the quartets of that class (three atoms, artificial s/p/d/f/g basis, the reference autotuner's kind of
     test system, jqc/backend/data/generate_fragment.py:97-114) -- for each of the five builds of a class kernel: J+K,
-    J only, K only, long-range (omega = 0.3) and fp32.  A miscompiled or racy class kernel shows up here even when the
-    common molecules never reach it ((gg|fp) did)."""
+    J only, K only, long-range (omega = 0.3) and fp32, plus the long-range K-only build the RKS ``get_veff`` asks for
+    with range-separated hybrids and the long-range fp32 build.  Launches of this size take the small-launch scheme
+    table ("fp64_small"); the ``*_main`` modes force the main table (tuned on 112 atoms) with long ket chunks.
+    A miscompiled or racy class kernel shows up here even when the common molecules never reach it ((gg|fp) did)."""
     import os
     from joltqc_amd.pyscf import jk as jkmod
     from oracle import dense
@@ -297,9 +299,13 @@ def test_every_angular_class_against_the_oracle(mode):
     dm = _dm(mol.nao)
     allq = dense.canonical_quartets(lay)
     qa = np.asarray(lay.angs)[allq.astype(int)]
-    with_j, with_k = mode != "k", mode != "j"
-    omega = 0.3 if mode == "lr" else None
-    cut64, tol = (1e100, 2e-5) if mode == "fp32" else (1e-13, 1e-11)      # fp32: every quartet through the fp32 kernels
+    main = mode.endswith("_main")
+    if main:
+        monkeypatch.setattr(jkmod, "TARGET_WGS", 1)        # no launch counts as small; ket chunks up to KCHUNK_MAX
+        mode = mode[:-5]
+    with_j, with_k = mode not in ("k", "k_lr"), mode != "j"
+    omega = 0.3 if mode.endswith("lr") else None
+    cut64, tol = (1e100, 2e-5) if mode.startswith("fp32") else (1e-13, 1e-11)      # fp32: every quartet through the fp32 kernels
     bad, nclass = [], 0
     try:
         for li in range(5):

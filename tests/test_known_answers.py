@@ -5,7 +5,7 @@ import pytest
 
 from joltqc_amd.gto import mole
 from joltqc_amd.pyscf.basis import BasisLayout
-from joltqc_amd.scf import RHF
+from standin_scf import RHF
 from oracle import dense
 
 
