@@ -114,7 +114,7 @@ def cpu_baseline(mol, layout, per_class, seconds=15.0):
     dm = rng.random((layout.nao, layout.nao))
     dm = dm + dm.T
     O.jk_raw(layout.packed, dm, sample_quartets(layout, per_class, 2000, rng), nthreads=cores)          # warm-up / library load
-    batch = 20000 * cores
+    batch = 4000 * cores
     done, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         O.jk_raw(layout.packed, dm, sample_quartets(layout, per_class, batch, rng), nthreads=cores)

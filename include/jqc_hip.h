@@ -28,6 +28,7 @@ extern "C" {
 #define JQC_ALGO_TILE 1 /* lane-group per quartet, LDS Fock tiles (replaces jk_1qnt.py / jk/1qnt.cu) */
 #define JQC_ALGO_TILE1Q 2 /* one quartet per lane inside the same LDS tile framework (small classes) */
 #define JQC_ALGO_TILE512 3 /* JQC_ALGO_TILE with 512-thread workgroups: two waves per SIMD on one set of LDS tiles */
+#define JQC_ALGO_PAIRVJ 8  /* pair-based J kernel (jqc_gen_pair_vj_kernel) */
 /* Tuning variant of a tiled kernel, OR-ed into the `algo` argument of jqc_gen_jk_kernel (gfx950 scheme table): */
 #define JQC_VARIANT_MINW(n) ((n) << 4) /* waves per SIMD the register allocation leaves room for (0 = kernel default) */
 #define JQC_VARIANT_RYS_L2 (1 << 8)    /* read the Rys table through L2 instead of staging it in LDS */
@@ -36,6 +37,13 @@ extern "C" {
 #define JQC_VARIANT_CJR (1 << 11)      /* row-lane mode, lane = bra component i only, the j components in registers (small kets) */
 #define JQC_VARIANT_NKS(log2n) ((log2n) << 12) /* lane-per-quartet mode: 2 (log2n=1) or 4 (2) ket tile pairs staged and screened
                                           per iteration, so classes with few candidates per tile pair still fill 256 lanes */
+
+#define JQC_VARIANT_QIL (1 << 14)  /* lane-per-quartet mode: strided read of the survivor queue (neighbouring lanes take quartets
+                                      of different ket slots) + four replicas of the J_ij tile: fewer same-address LDS atomics */
+#define JQC_VARIANT_CORD (1 << 15) /* lane-per-quartet mode: contraction row by row with the next row's density reads issued
+                                      before the current row's LDS atomics */
+#define JQC_VARIANT_ECAP(code) ((code) << 16) /* row-lane mode: integrals held per lane and chunk capped at 64 (0), 32 (1), 16 (2)
+                                      or 48 (3): smaller chunks re-read the TRR array from LDS but keep the lane out of scratch */
 
 const char* jqc_last_error(void);
 const char* jqc_version(void);
@@ -118,6 +126,36 @@ int jqc_shell_block_max(const double* mat_d, int n_dm, int nao, const int32_t* a
 int jqc_pair_table(const double* basis_d, const uint32_t* tpair_sh_d, const uint32_t* tpair_wij_d,
                    const uint32_t* pp_off_d, int npairs, double* out_d, void* stream);
 
+/* One-electron integrals (overlap S, kinetic T, nuclear attraction V) of n shell pairs (ish << 16 | jsh, ish >= jsh) in the
+ * internal Cartesian basis, [nao, nao] each, both triangles written.  atoms_d = [x, y, z, Z] per nucleus (Bohr).  The
+ * reference takes these from PySCF/libcint on the CPU (mf.get_hcore / get_ovlp); SURVEY.md 8f row 1. */
+int jqc_int1e(const double* basis_d, const int32_t* ao_loc_d, const uint32_t* pairs_d, int npairs, const double* atoms_d,
+              int natm, int nao, double* S_d, double* T_d, double* V_d, void* stream);
+
+/* ---- pair-based Coulomb path (second J algorithm: jqc/backend/jk_pair.py:288-371 gen_vj_kernel, jk/pair_vj.cu:43-465) ----
+ * A lane owns one bra shell pair and walks the Schwarz-sorted ket pair list; J_ij stays in registers.  The density is folded
+ * into the ket side once per call by jqc_pair_ket_density (E coefficients over the combined ket index, see pair_vj.hip).
+ *
+ * jqc_gen_pair_vj_kernel: handle of the (li lj | lk ll) kernel, li >= lj, lk >= ll (no li >= lk restriction: bra and ket
+ * classes are independent here).  Returns -4 (and builds nothing loadable) when the class does not fit the register file
+ * without scratch: the caller keeps such classes on the tiled kernels. */
+int jqc_gen_pair_vj_kernel(int li, int lj, int lk, int ll, int rys_lr, int compile_only);
+/* number of E coefficients per ket pair of angular momenta (lk, ll): triples (cx,cy,cz), lk <= cx+cy+cz <= lk+ll */
+int jqc_pair_ntrip(int lk, int ll);
+/* E_d[pair][ntrip] and ld_d[pair] = log max|D_kl| for n_ket pairs (ksh << 16 | lsh) of one angular class; dm_d is the
+ * SYMMETRISED density [nao, nao] in the internal Cartesian order. */
+int jqc_pair_ket_density(const double* basis_d, const double* dm_d, int nao, const uint32_t* ket_pairs_d, int n_ket, int lk,
+                         int ll, double* E_d, float* ld_d, void* stream);
+/* vj_d[(j0+j)*nao + i0+i] += raw J_ij of every bra pair (same raw convention as the tiled kernels: the epilogue doubles and
+ * adds the transpose).  Bra list: ONE (l, nprim) group pair (npi, npj uniform), sorted by bound; ket list: ket_seg_d[2 s],
+ * [2 s + 1] = first entry / length of sorted segment s inside ket_pairs_d / ket_q_d / ket_ld_d / ket_tab_d / E_d.
+ * *_tab_d: 27 doubles per pair (jqc_pair_table with 1 x 1 tiles).  nsplit workgroups share a block of 256 bra pairs. */
+int jqc_pair_vj_launch(int handle, int nao, const double* basis_d, const double* E_d, double* vj_d, double omega,
+                       const uint32_t* bra_pairs_d, int n_bra, const float* bra_q_d, const double* bra_tab_d,
+                       const uint32_t* ket_pairs_d, const float* ket_q_d, const float* ket_ld_d, const double* ket_tab_d,
+                       const int32_t* ket_seg_d, int nseg, float log_cut, float log_max_dm, int npi, int npj, int nsplit,
+                       uint64_t* counter_d, void* stream);
+
 /* Schwarz bounds on device (replaces the libcvhf call in compute_q_matrix, jqc/pyscf/basis.py:840-867):
  * for each listed pair p = (ish<<16|jsh) with l(ish)=li, l(jsh)=lj:  out[p] = sqrt(max_ab |(ab|ab)|). */
 int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d, int npairs, double omega,
@@ -142,17 +180,20 @@ int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d
  * jqc_vv10           replaces vv10_kernel (jqc/backend/rks.py:250-335, dft/vv10.cu:29): F,U,W double[ngrids]. */
 int jqc_dft_ao_screen(const double* coords_d, int ngrids, const double* basis_d, const int32_t* ao_loc_d, int nbas,
                       float log_cutoff, uint16_t* shell_list_d, int32_t* row_of_d, int32_t* nshl_d, int32_t* nrow_d,
-                      void* stream);
+                      float* shell_la_d, void* stream);
 int jqc_dft_eval_ao(const double* coords_d, int ngrids, const double* basis_d, int nbas, int blk0, int nblk,
                     const uint16_t* shell_list_d, const int32_t* row_of_d, const int32_t* nshl_d, const int32_t* nrow_d,
                     const int64_t* row_base_d, int ncomp, int64_t comp_stride, double* ws_d, int32_t* ao_idx_d,
-                    void* stream);
+                    const float* shell_la_d, float* row_la_d, void* stream);
+/* row_la_d: log estimate of every workspace row (sorted, largest first, per block); AO pairs (a, b) of a block with
+ * la_a + la_b above thr64 are contracted in FP64, between thr32 and thr64 in FP32 (MFMA f32), below thr32 not at all
+ * (the reference's [cutoff_a, cutoff_b) windows, eval_rho.cu:93-106; thr = log cutoff - log max|D| resp. log max|wv|). */
 int jqc_dft_rho(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                 const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, int ndim, double* rho_d,
-                void* stream);
+                const float* row_la_d, float thr64, float thr32, void* stream);
 int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                 const double* ws_d, const int32_t* ao_idx_d, const double* wv_d, int ndim, int nao, double* vmat_d,
-                void* stream);
+                const float* row_la_d, float thr64, float thr32, void* stream);
 int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, const double* coords_d,
              const double* W0p_d, const double* W0_d, const double* K_d, const double* Kp_d, const double* RpW_d,
              int vvngrids, int ngrids, int fp32, void* stream);

@@ -57,8 +57,11 @@ def forced_variant(ang, v):
     the wave-local variant only where a quartet fits one wave."""
     if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > TILE1Q_FORCE_MAX:
         return _lib.ALGO_TILE
+    if (v & 0xf) == _lib.ALGO_TILE1Q:
+        v &= ~0x30000                                 # integral chunks: row-lane mode only
     if (v & 0xf) != _lib.ALGO_TILE1Q:
-        v &= ~0x3000                                  # several ket pairs per iteration: lane-per-quartet mode only
+        v &= ~0xf000                                  # several ket pairs per iteration, strided queue, row-ordered contraction:
+                                                      # lane-per-quartet mode only
     nf = lambda l: (l + 1) * (l + 2) // 2
     if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or nf(ang[0]) * nf(ang[1]) > 64):
         v &= ~0x400

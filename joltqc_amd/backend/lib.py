@@ -16,7 +16,7 @@ CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 # that the verified AOT set of the shipped sources stays usable until a change is adopted
 KERNEL_SRC = os.environ.get("JQC_KERNEL_SRC", os.path.join(CSRC, "kernels"))
 KERNEL_CACHE = os.environ.get("JQC_KERNEL_CACHE", os.path.join(CSRC, "kcache" if "JQC_KERNEL_SRC" not in os.environ else "kcache_dev"))
-LIB_PATH = os.path.join(CSRC, "libjqc_hip.so")
+LIB_PATH = os.environ.get("JQC_LIB_PATH", os.path.join(CSRC, "libjqc_hip.so"))      # (override: a development build)
 
 ALGO_1Q1T = 0
 ALGO_TILE = 1
@@ -68,10 +68,16 @@ def lib():
         L.jqc_screen_jk_tasks.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp]
         L.jqc_shell_block_max.argtypes = [vp, i32, i32, vp, i32, vp, vp]
         L.jqc_schwarz.argtypes = [i32, i32, vp, vp, i32, f64, vp, vp]
-        L.jqc_dft_ao_screen.argtypes = [vp, i32, vp, vp, i32, f32, vp, vp, vp, vp, vp]
-        L.jqc_dft_eval_ao.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp]
-        L.jqc_dft_rho.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp]
-        L.jqc_dft_vxc.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp]
+        L.jqc_int1e.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
+        L.jqc_gen_pair_vj_kernel.argtypes = [i32] * 6
+        L.jqc_pair_ntrip.argtypes = [i32, i32]
+        L.jqc_pair_ket_density.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp, vp]
+        L.jqc_pair_vj_launch.argtypes = [i32, i32, vp, vp, vp, f64, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, i32,
+                                         i32, vp, vp]
+        L.jqc_dft_ao_screen.argtypes = [vp, i32, vp, vp, i32, f32, vp, vp, vp, vp, vp, vp]
+        L.jqc_dft_eval_ao.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp]
+        L.jqc_dft_rho.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp, f32, f32, vp]
+        L.jqc_dft_vxc.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp, f32, f32, vp]
         L.jqc_vv10.argtypes = [vp] * 10 + [i32, i32, i32, vp]
         from ..constants import TILE_WIDTHS
         L.jqc_set_tile_widths.argtypes = [c.POINTER(c.c_int)]

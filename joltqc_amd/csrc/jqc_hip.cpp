@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <map>
 #include <mutex>
@@ -55,8 +56,23 @@ struct Kernel {
     hipFunction_t fn = nullptr;
     int li = 0, lj = 0, lk = 0, ll = 0, fp32 = 0, algo = 0, nroots = 1;
 };
-std::vector<Kernel> g_kernels;
+// a deque: handles stay valid and references to entries are not moved when another thread registers a kernel; every
+// access to the container itself (size, lookup, push_back) happens under g_mu, the launchers copy the few fields they need
+std::deque<Kernel> g_kernels;
 std::map<std::string, int> g_by_key;
+
+struct KernelView { hipFunction_t fn; int fp32, algo, nroots; };
+bool kernel_view(int handle, KernelView& v)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (handle < 0 || handle >= (int)g_kernels.size() || !g_kernels[handle].fn) return false;
+    const Kernel& k = g_kernels[handle];
+    v = KernelView{k.fn, k.fp32, k.algo, k.nroots};
+    return true;
+}
+
+// the fixed hiprtc option set (part of the source tag: a code object built with other options is another build)
+const char* const kHiprtcOpts[] = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-ffp-contract=fast"};
 
 // device copies of the Rys tables
 double* g_rys64 = nullptr;
@@ -86,8 +102,8 @@ int compile_code(const std::string& src_name, const std::vector<std::string>& de
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), src_name.c_str(), 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(-3, "hiprtcCreateProgram failed");
-    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-ffp-contract=fast",
-                                     "-I" + g_src_dir};
+    std::vector<std::string> opts(std::begin(kHiprtcOpts), std::end(kHiprtcOpts));
+    opts.push_back("-I" + g_src_dir);
     for (auto& d : defs) opts.push_back(d);
     if (const char* extra = getenv("JQC_EXTRA_DEFS")) {      // tuning experiments: e.g. "-DMINW=3 -DECAP=32"
         std::stringstream ss(extra);
@@ -290,6 +306,208 @@ shell_block_max_kernel(const double* __restrict__ mat, const int n_dm, const int
     out[idx] = (float)m;
 }
 
+// E coefficients of the pair-based J kernel (pair_vj.hip): per ket pair (k >= l)
+//   E[cx,cy,cz] = (2 - delta_kl) sum_{k comp, l comp} D[l, k] Hx(kx,lx;cx) Hy(ky,ly;cy) Hz(kz,lz;cz),
+//   H(k,l;c) = C(l, c-k) (R_k - R_l)^(l-c+k)    (ket horizontal recurrence g(k,l+1) = g(k+1,l) - (R_l - R_k) g(k,l) unrolled),
+// triples ordered by total cx+cy+cz = lk..lk+ll ascending, cx descending, cy descending.  One lane per ket pair.
+__global__ void __launch_bounds__(64)
+pair_ket_density_kernel(const double* __restrict__ basis, const double* __restrict__ dm, const int nao,
+                        const unsigned* __restrict__ ket_pairs, const int n_ket, const int lk, const int ll,
+                        double* __restrict__ E, float* __restrict__ ld)
+{
+    const int kt = blockIdx.x * 64 + threadIdx.x;
+    if (kt >= n_ket) return;
+    const unsigned p = ket_pairs[kt];
+    const int ksh = p >> 16, lsh = p & 0xffff;
+    const double* bk = basis + (size_t)ksh * 12;
+    const double* bl = basis + (size_t)lsh * 12;
+    const int k0 = (int)bk[3], l0 = (int)bl[3];
+    const int lkl = lk + ll;
+    // H[ax][k][l][c]
+    double H[3][5][5][9];
+    for (int ax = 0; ax < 3; ax++) {
+        const double r = bk[ax] - bl[ax];
+        for (int k = 0; k <= lk; k++)
+            for (int l = 0; l <= ll; l++)
+                for (int c = 0; c <= lkl; c++) {
+                    const int m = c - k;
+                    double v = 0;
+                    if (m >= 0 && m <= l) {
+                        double binom = 1;
+                        for (int q = 0; q < m; q++) binom = binom * (l - q) / (q + 1);
+                        v = binom;
+                        for (int q = 0; q < l - m; q++) v *= r;
+                    }
+                    H[ax][k][l][c] = v;
+                }
+    }
+    const double f = ksh == lsh ? 1.0 : 2.0;
+    const int nfk = (lk + 1) * (lk + 2) / 2, nfl = (ll + 1) * (ll + 2) / 2;
+    int ntrip = 0;
+    for (int t = lk; t <= lkl; t++) ntrip += (t + 1) * (t + 2) / 2;
+    double* out = E + (size_t)kt * ntrip;
+    double dmax = 0;
+    int n = 0;
+    for (int tot = lk; tot <= lkl; tot++)
+        for (int cx = tot; cx >= 0; cx--)
+            for (int cy = tot - cx; cy >= 0; cy--, n++) {
+                const int cz = tot - cx - cy;
+                double s = 0;
+                int kc = 0;
+                for (int kx = lk; kx >= 0; kx--)
+                    for (int ky = lk - kx; ky >= 0; ky--, kc++) {
+                        const int kz = lk - kx - ky;
+                        int lc = 0;
+                        for (int lx = ll; lx >= 0; lx--)
+                            for (int ly = ll - lx; ly >= 0; ly--, lc++) {
+                                const int lz = ll - lx - ly;
+                                const double d = dm[(size_t)(l0 + lc) * nao + k0 + kc];
+                                if (n == 0) dmax = fmax(dmax, fabs(d));
+                                s += d * H[0][kx][lx][cx] * H[1][ky][ly][cy] * H[2][kz][lz][cz];
+                            }
+                    }
+                out[n] = f * s;
+            }
+    (void)nfk; (void)nfl;
+    ld[kt] = (float)log(dmax + 1e-300);
+}
+
+// One-electron integrals S, T, V of every shell pair (i >= j) in the internal Cartesian basis (the
+// last CPU / libcint step before the Fock build; the reference takes them from PySCF).  One lane per shell pair, run-time
+// angular momenta (a once-per-geometry kernel).  Obara-Saika recurrences for overlap and kinetic energy; nuclear attraction
+// by Rys quadrature with the same tables as the ERIs: V_ab = -sum_C Z_C 2 pi / p K_ab sum_r w_r Ix Iy Iz,
+// I(i+1,0) = (PA - t_r^2 PC) I(i,0) + i (1 - t_r^2) / (2p) I(i-1,0), roots at x = p |PC|^2.
+// Cartesian order and normalisation are those of the packed shell table (s, p coefficients carry sqrt((2l+1)/4pi)).
+__global__ void __launch_bounds__(64)
+int1e_kernel(const double* __restrict__ basis, const int* __restrict__ ao_loc, const unsigned* __restrict__ pairs, const int npairs,
+             const double* __restrict__ atoms, const int natm, const int nao, const double* __restrict__ rys, const double* __restrict__ rys_hdr,
+             double* __restrict__ S, double* __restrict__ T, double* __restrict__ V)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= npairs) return;
+    const unsigned p = pairs[t];
+    const int ish = p >> 16, jsh = p & 0xffff;
+    const double* bi = basis + (size_t)ish * 12;
+    const double* bj = basis + (size_t)jsh * 12;
+    const int li = (int)bi[11], lj = (int)bj[11], npi = (int)bi[10], npj = (int)bj[10];
+    const int nfi = (li + 1) * (li + 2) / 2, nfj = (lj + 1) * (lj + 2) / 2;
+    const int i0 = ao_loc[ish], j0 = ao_loc[jsh];
+    const double A[3] = {bi[0], bi[1], bi[2]}, B[3] = {bj[0], bj[1], bj[2]};
+    const double AB[3] = {A[0] - B[0], A[1] - B[1], A[2] - B[2]};
+    const double r2 = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
+    double s_blk[15 * 15], t_blk[15 * 15], v_blk[15 * 15];
+    for (int n = 0; n < nfi * nfj; n++) s_blk[n] = t_blk[n] = v_blk[n] = 0;
+    const int nroots = (li + lj) / 2 + 1;
+    const double* cheb = rys + (long)rys_hdr[2 * nroots - 1];
+    const double* large = rys + (long)rys_hdr[2 * nroots];
+    for (int ip = 0; ip < npi; ip++)
+    for (int jp = 0; jp < npj; jp++) {
+        const double a = bi[5 + 2 * ip], b = bj[5 + 2 * jp], cc = bi[4 + 2 * ip] * bj[4 + 2 * jp];
+        const double pp = a + b, ip2 = 0.5 / pp;
+        const double K = cc * exp(-a * b / pp * r2);
+        double P[3], PA[3];
+        for (int x = 0; x < 3; x++) { P[x] = (a * A[x] + b * B[x]) / pp; PA[x] = P[x] - A[x]; }
+        // ---- overlap 1-D integrals s[x][i][j], i <= li, j <= lj + 2 (kinetic needs j + 2)
+        double s1[3][5][7];
+        const double s00 = sqrt(3.14159265358979323846 / pp);
+        for (int x = 0; x < 3; x++) {
+            double col[12];                       // (m, 0), m <= li + lj + 2
+            col[0] = s00;
+            col[1] = PA[x] * s00;
+            for (int m = 1; m < li + lj + 2; m++) col[m + 1] = PA[x] * col[m] + m * ip2 * col[m - 1];
+            // (i, j+1) = (i+1, j) + (A - B) (i, j)
+            double w[12];
+            for (int m = 0; m <= li + lj + 2; m++) w[m] = col[m];
+            for (int j = 0; j <= lj + 2; j++) {
+                for (int i = 0; i <= li; i++) s1[x][i][j] = w[i];
+                for (int m = 0; m < li + lj + 2 - j; m++) w[m] = w[m + 1] + AB[x] * w[m];
+            }
+        }
+        // kinetic 1-D: t(i,j) = -2 b^2 s(i,j+2) + b (2j+1) s(i,j) - j(j-1)/2 s(i,j-2)
+        double t1[3][5][5];
+        for (int x = 0; x < 3; x++)
+            for (int i = 0; i <= li; i++)
+                for (int j = 0; j <= lj; j++)
+                    t1[x][i][j] = -2.0 * b * b * s1[x][i][j + 2] + b * (2 * j + 1) * s1[x][i][j] -
+                                  (j >= 2 ? 0.5 * j * (j - 1) * s1[x][i][j - 2] : 0.0);
+        int ci = 0;
+        for (int ix = li; ix >= 0; ix--)
+        for (int iy = li - ix; iy >= 0; iy--, ci++) {
+            const int iz = li - ix - iy;
+            int cj = 0;
+            for (int jx = lj; jx >= 0; jx--)
+            for (int jy = lj - jx; jy >= 0; jy--, cj++) {
+                const int jz = lj - jx - jy;
+                const double sx = s1[0][ix][jx], sy = s1[1][iy][jy], sz = s1[2][iz][jz];
+                s_blk[ci * nfj + cj] += K * sx * sy * sz;
+                t_blk[ci * nfj + cj] += K * (t1[0][ix][jx] * sy * sz + sx * t1[1][iy][jy] * sz + sx * sy * t1[2][iz][jz]);
+            }
+        }
+        // ---- nuclear attraction
+        for (int c = 0; c < natm; c++) {
+            const double Z = atoms[4 * c + 3];
+            const double PC[3] = {P[0] - atoms[4 * c], P[1] - atoms[4 * c + 1], P[2] - atoms[4 * c + 2]};
+            const double x = pp * (PC[0] * PC[0] + PC[1] * PC[1] + PC[2] * PC[2]);
+            double rw[18];
+            // roots (t^2) and weights at x (same tables / branches as rys_roots in kernels/jk_common.h)
+            if (x >= 5 * nroots + 35) {
+                const double isx = 1.0 / sqrt(x), ix2 = isx * isx;
+                for (int r = 0; r < nroots; r++) { rw[2 * r] = large[2 * r] * ix2; rw[2 * r + 1] = large[2 * r + 1] * isx; }
+            } else {
+                const int it = (int)(x * 0.4);
+                const double u = (x - 2.5 * it) * 0.8 - 1.0, u2 = u + u;
+                const double* cf = cheb + (size_t)it * nroots * 28;
+                for (int r = 0; r < nroots; r++, cf += 28) {
+                    double br1 = 0, br2 = 0, bw1 = 0, bw2 = 0;
+                    for (int k = 13; k >= 1; k--) {
+                        double q = cf[2 * k] + u2 * br1 - br2; br2 = br1; br1 = q;
+                        q = cf[2 * k + 1] + u2 * bw1 - bw2; bw2 = bw1; bw1 = q;
+                    }
+                    rw[2 * r] = cf[0] + u * br1 - br2;
+                    rw[2 * r + 1] = cf[1] + u * bw1 - bw2;
+                }
+            }
+            const double pref = -Z * K * 2.0 * 3.14159265358979323846 / pp;
+            for (int r = 0; r < nroots; r++) {
+                // the tables hold weights of int_0^1 with the ERI convention sum_r w_r = F_0(x) (tests/test_rys.py)
+                const double t2 = rw[2 * r], wt = rw[2 * r + 1];
+                double g[3][5][5];
+                for (int xx = 0; xx < 3; xx++) {
+                    double col[9];
+                    const double c0 = PA[xx] - t2 * PC[xx], b10 = ip2 * (1.0 - t2);
+                    col[0] = 1.0;
+                    col[1] = c0;
+                    for (int m = 1; m < li + lj; m++) col[m + 1] = c0 * col[m] + m * b10 * col[m - 1];
+                    double w[9];
+                    for (int m = 0; m <= li + lj; m++) w[m] = col[m];
+                    for (int j = 0; j <= lj; j++) {
+                        for (int i = 0; i <= li; i++) g[xx][i][j] = w[i];
+                        for (int m = 0; m < li + lj - j; m++) w[m] = w[m + 1] + AB[xx] * w[m];
+                    }
+                }
+                int ci2 = 0;
+                for (int ix = li; ix >= 0; ix--)
+                for (int iy = li - ix; iy >= 0; iy--, ci2++) {
+                    const int iz = li - ix - iy;
+                    int cj = 0;
+                    for (int jx = lj; jx >= 0; jx--)
+                    for (int jy = lj - jx; jy >= 0; jy--, cj++) {
+                        const int jz = lj - jx - jy;
+                        v_blk[ci2 * nfj + cj] += pref * wt * g[0][ix][jx] * g[1][iy][jy] * g[2][iz][jz];
+                    }
+                }
+            }
+        }
+    }
+    for (int ci = 0; ci < nfi; ci++)
+        for (int cj = 0; cj < nfj; cj++) {
+            const size_t ij = (size_t)(i0 + ci) * nao + j0 + cj, ji = (size_t)(j0 + cj) * nao + i0 + ci;
+            S[ij] = S[ji] = s_blk[ci * nfj + cj];
+            T[ij] = T[ji] = t_blk[ci * nfj + cj];
+            V[ij] = V[ji] = v_blk[ci * nfj + cj];
+        }
+}
+
 #include "dft_kernels.inc"
 
 }  // namespace
@@ -308,13 +526,24 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
     g_cache_dir = cache_dir ? cache_dir : "";
     if (!g_cache_dir.empty()) mkdir(g_cache_dir.c_str(), 0755);
     unsigned long long h = 1469598103934665603ull;
-    for (const char* f : {"jk_common.h", "jk_axis.h", "jk_1q1t.hip", "jk_tile.hip", "schwarz.hip"}) {
+    for (const char* f : {"jk_common.h", "jk_axis.h", "jk_1q1t.hip", "jk_tile.hip", "schwarz.hip", "pair_vj.hip"}) {
         const std::string txt = read_file(g_src_dir + "/" + f);
         for (unsigned char ch : txt) { h ^= ch; h *= 1099511628211ull; }
     }
     if (const char* extra = getenv("JQC_EXTRA_DEFS"))
         for (const char* c = extra; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
     for (const char* c = "build-policy:karg-reload-iff-scratch"; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+    // compiler version and option set: register allocation decides which builds pass the gates, so code
+    // objects of another hiprtc are other builds -- not reused from the cache, not covered by the verified manifest
+    {
+        int major = 0, minor = 0;
+        (void)hiprtcVersion(&major, &minor);
+        char ver[64];
+        snprintf(ver, sizeof ver, "hiprtc-%d.%d", major, minor);
+        for (const char* c = ver; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+        for (const char* o : kHiprtcOpts)
+            for (const char* c = o; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+    }
     char tag[32];
     snprintf(tag, sizeof tag, "%010llx", h & 0xffffffffffull);
     g_src_tag = tag;
@@ -355,6 +584,8 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     const int v_minw = (algo_variant >> 4) & 0xf;
     const int v_rys_l2 = (algo_variant >> 8) & 1, v_st1 = (algo_variant >> 9) & 1, v_wsync = (algo_variant >> 10) & 1, v_cjr = (algo_variant >> 11) & 1;
     const int v_nks = (algo_variant >> 12) & 3;
+    const int v_qil = (algo_variant >> 14) & 1, v_cord = (algo_variant >> 15) & 1;
+    const int v_ecap = (algo_variant >> 16) & 3;
     if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
     if (!do_j && !do_k) return fail(-1, "need do_j or do_k");
@@ -385,6 +616,9 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
         if (v_wsync) d.push_back("-DWSYNC=1");
         if (v_cjr) d.push_back("-DCJR=1");
         if (v_nks) d.push_back("-DNKS=" + std::to_string(1 << v_nks));
+        if (v_qil) d.push_back("-DQIL=1");
+        if (v_cord) d.push_back("-DCORD=1");
+        if (v_ecap) d.push_back(std::string("-DECAP=") + (v_ecap == 1 ? "32" : v_ecap == 2 ? "16" : "48"));
         if (tiled) {
             // Builds that spill vector registers to scratch also re-read the staging pointers from the kernarg segment
             // (KARG_RELOAD in jk_tile.hip: ~45 fewer SGPRs spilled to VGPR lanes); builds without scratch keep the
@@ -429,11 +663,10 @@ int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, do
                   double omega, const void* quartets_d, const uint32_t* ntasks_d, int64_t ntasks_max, int qstride,
                   int n_dm, void* stream)
 {
-    if (handle < 0 || handle >= (int)g_kernels.size() || !g_kernels[handle].fn)
-        return fail(-1, "invalid kernel handle %d", handle);
+    KernelView k;
+    if (!kernel_view(handle, k)) return fail(-1, "invalid kernel handle %d", handle);
     if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
     if (ntasks_max <= 0) return 0;
-    const Kernel& k = g_kernels[handle];
     const int n = k.nroots;
     float omega_f = (float)omega;
     const void* cheb = k.fp32 ? (const void*)rys_cheb32(n) : (const void*)rys_cheb64(n);
@@ -454,14 +687,13 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
                        float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, const int32_t* blk_index_d,
                        const uint32_t* tpair_ao_d, const uint32_t* tpair_pp_d, const void* pair_tab_d, void* stream)
 {
-    if (handle < 0 || handle >= (int)g_kernels.size() || !g_kernels[handle].fn)
-        return fail(-1, "invalid kernel handle %d", handle);
-    if (g_kernels[handle].algo != JQC_ALGO_TILE && g_kernels[handle].algo != JQC_ALGO_TILE1Q &&
-        g_kernels[handle].algo != JQC_ALGO_TILE512)
+    KernelView k;
+    if (!kernel_view(handle, k)) return fail(-1, "invalid kernel handle %d", handle);
+    if (k.algo != JQC_ALGO_TILE && k.algo != JQC_ALGO_TILE1Q && k.algo != JQC_ALGO_TILE512)
         return fail(-1, "handle %d is not a tile kernel", handle);
     if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
+    if (nbas > 46340) return fail(-1, "nbas = %d: the kernels index nbas x nbas tables with 32-bit integers (limit 46340)", nbas);
     if (ntasks <= 0 || nblocks <= 0) return 0;
-    const Kernel& k = g_kernels[handle];
     const int n = k.nroots;
     float omega_f = (float)omega;
     const void* cheb = k.fp32 ? (const void*)rys_cheb32(n) : (const void*)rys_cheb64(n);
@@ -471,6 +703,116 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
                     &cheb, &large, &counter_d, &blk_index_d, &tpair_ao_d, &tpair_pp_d, &pair_tab_d};
     const unsigned threads = k.algo == JQC_ALGO_TILE512 ? 512 : 256;
     HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)nblocks, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+    return 0;
+}
+
+int jqc_pair_ntrip(int lk, int ll)
+{
+    int n = 0;
+    for (int t = lk; t <= lk + ll; t++) n += (t + 1) * (t + 2) / 2;
+    return n;
+}
+
+int jqc_gen_pair_vj_kernel(int li, int lj, int lk, int ll, int rys_lr, int compile_only)
+{
+    std::lock_guard<std::mutex> lk_(g_mu);
+    if (li > JQC_LMAX || lk > JQC_LMAX || lj > li || ll > lk || lj < 0 || ll < 0)
+        return fail(-1, "unsupported pair class (%d%d|%d%d): need LMAX >= li >= lj, LMAX >= lk >= ll", li, lj, lk, ll);
+    char key[96];
+    snprintf(key, sizeof key, "pairvj_%d%d%d%d_lr%d", li, lj, lk, ll, rys_lr);
+    auto it = g_by_key.find(key);
+    if (it != g_by_key.end()) {
+        const Kernel& k = g_kernels[it->second];
+        if (k.algo == -JQC_ALGO_PAIRVJ) return fail(-4, "pair_vj %s needs scratch: class stays on the tiled kernels", key);
+        if (compile_only || k.fn) return it->second;
+    }
+    char entry[64];
+    snprintf(entry, sizeof entry, "pair_vj_%d%d%d%d", li, lj, lk, ll);
+    const std::string out = g_cache_dir + "/" + key + "_" + g_src_tag + ".hsaco";
+    const std::string none = out + ".scratch";            // marker: the build spills, never load it
+    Kernel k;
+    k.key = key;
+    k.li = li; k.lj = lj; k.lk = lk; k.ll = ll; k.algo = JQC_ALGO_PAIRVJ;
+    k.nroots = (li + lj + lk + ll) / 2 + 1;
+    if (!file_exists(out) && !file_exists(none)) {
+        std::vector<std::string> d = {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
+                                      "-DLK=" + std::to_string(lk), "-DLL=" + std::to_string(ll),
+                                      "-DRYS_LR=" + std::to_string(rys_lr), "-DFP32=0", std::string("-DKNAME=") + entry};
+        // register budget: as many waves per SIMD as the class allows without scratch (latency of the scalar ket loads)
+        std::string code;
+        bool ok = false;
+        for (int minw : {4, 2, 1}) {
+            d.push_back("-DMINW=" + std::to_string(minw));
+            int rc = compile_code("pair_vj.hip", d, code);
+            d.pop_back();
+            if (rc) return rc;
+            if (scratch_bytes(code) == 0) { ok = true; break; }
+        }
+        int rc = write_code(ok ? code : std::string("scratch\n"), ok ? out : none);
+        if (rc) return rc;
+    }
+    if (!file_exists(out)) {
+        k.algo = -JQC_ALGO_PAIRVJ;
+        if (it == g_by_key.end()) { g_kernels.push_back(k); g_by_key[key] = (int)g_kernels.size() - 1; }
+        return fail(-4, "pair_vj %s needs scratch: class stays on the tiled kernels", key);
+    }
+    if (!compile_only) {
+        int rc = load_kernel(out, entry, k);
+        if (rc) return rc;
+    }
+    int h;
+    if (it != g_by_key.end()) {
+        h = it->second;
+        g_kernels[h] = k;
+    } else {
+        h = (int)g_kernels.size();
+        g_kernels.push_back(k);
+        g_by_key[key] = h;
+    }
+    return h;
+}
+
+int jqc_pair_ket_density(const double* basis_d, const double* dm_d, int nao, const uint32_t* ket_pairs_d, int n_ket, int lk,
+                         int ll, double* E_d, float* ld_d, void* stream)
+{
+    if (n_ket <= 0) return 0;
+    if (lk > JQC_LMAX || ll > lk || ll < 0) return fail(-1, "unsupported ket class (%d%d)", lk, ll);
+    hipLaunchKernelGGL(pair_ket_density_kernel, dim3((n_ket + 63) / 64), dim3(64), 0, (hipStream_t)stream, basis_d, dm_d, nao,
+                       ket_pairs_d, n_ket, lk, ll, E_d, ld_d);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int jqc_pair_vj_launch(int handle, int nao, const double* basis_d, const double* E_d, double* vj_d, double omega,
+                       const uint32_t* bra_pairs_d, int n_bra, const float* bra_q_d, const double* bra_tab_d,
+                       const uint32_t* ket_pairs_d, const float* ket_q_d, const float* ket_ld_d, const double* ket_tab_d,
+                       const int32_t* ket_seg_d, int nseg, float log_cut, float log_max_dm, int npi, int npj, int nsplit,
+                       uint64_t* counter_d, void* stream)
+{
+    KernelView k;
+    if (!kernel_view(handle, k)) return fail(-1, "invalid kernel handle %d", handle);
+    if (k.algo != JQC_ALGO_PAIRVJ) return fail(-1, "handle %d is not a pair_vj kernel", handle);
+    if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
+    if (n_bra <= 0 || nseg <= 0) return 0;
+    if (nsplit < 1) nsplit = 1;
+    const double* cheb = rys_cheb64(k.nroots);
+    const double* large = rys_large64(k.nroots);
+    void* args[] = {&nao, &basis_d, &E_d, &vj_d, &omega, &bra_pairs_d, &n_bra, &bra_q_d, &bra_tab_d, &ket_pairs_d, &ket_q_d,
+                    &ket_ld_d, &ket_tab_d, &ket_seg_d, &nseg, &log_cut, &log_max_dm, &npi, &npj, &cheb, &large, &counter_d};
+    HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)((n_bra + 255) / 256), (unsigned)nsplit, 1, 256, 1, 1, 0, (hipStream_t)stream,
+                                 args, nullptr));
+    return 0;
+}
+
+int jqc_int1e(const double* basis_d, const int32_t* ao_loc_d, const uint32_t* pairs_d, int npairs, const double* atoms_d,
+              int natm, int nao, double* S_d, double* T_d, double* V_d, void* stream)
+{
+    if (npairs <= 0) return 0;
+    if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
+    // (the device blob starts with its own header: offsets of cheb_n / large_n, joltqc_amd/backend/rys.py)
+    hipLaunchKernelGGL(int1e_kernel, dim3((npairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, basis_d, ao_loc_d, pairs_d,
+                       npairs, atoms_d, natm, nao, (const double*)g_rys64, (const double*)g_rys64, S_d, T_d, V_d);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 
@@ -512,7 +854,8 @@ int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d
 {
     if (npairs <= 0) return 0;
     if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
-    Kernel* kp = nullptr;
+    hipFunction_t sfn = nullptr;
+    int snroots = 0;
     {
         std::lock_guard<std::mutex> lk_(g_mu);
         const int lr = omega > 0 ? 1 : 0;
@@ -535,13 +878,14 @@ int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d
             g_by_key[key] = (int)g_kernels.size() - 1;
             it = g_by_key.find(key);
         }
-        kp = &g_kernels[it->second];
+        sfn = g_kernels[it->second].fn;
+        snroots = g_kernels[it->second].nroots;
     }
-    const int n = kp->nroots;
+    const int n = snroots;
     const double* cheb = rys_cheb64(n);
     const double* large = rys_large64(n);
     void* args[] = {&basis_d, &pair_sh_d, &npairs, &omega, &out_d, &cheb, &large};
-    HIP_OK(hipModuleLaunchKernel(kp->fn, (unsigned)((npairs + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args,
+    HIP_OK(hipModuleLaunchKernel(sfn, (unsigned)((npairs + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args,
                                  nullptr));
     return 0;
 }
@@ -550,13 +894,13 @@ int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d
 // ------------------------------------------------------------------------------------------------ DFT grid path
 int jqc_dft_ao_screen(const double* coords_d, int ngrids, const double* basis_d, const int32_t* ao_loc_d, int nbas,
                       float log_cutoff, uint16_t* shell_list_d, int32_t* row_of_d, int32_t* nshl_d, int32_t* nrow_d,
-                      void* stream)
+                      float* shell_la_d, void* stream)
 {
     if (ngrids % NG) return fail(-1, "ngrids (%d) must be a multiple of %d", ngrids, NG);
-    if (nbas > 16384) return fail(-1, "more than 16384 shells are not supported by the grid screening kernel");
+    if (nbas > DFT_NBMAX) return fail(-1, "more than %d shells are not supported by the grid screening kernel", DFT_NBMAX);
     if (ngrids == 0) return 0;
     hipLaunchKernelGGL(ao_screen_kernel, dim3(ngrids / NG), dim3(256), 0, (hipStream_t)stream, coords_d, ngrids, basis_d,
-                       ao_loc_d, nbas, log_cutoff, shell_list_d, row_of_d, nshl_d, nrow_d);
+                       ao_loc_d, nbas, log_cutoff, shell_list_d, row_of_d, nshl_d, nrow_d, shell_la_d);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -564,36 +908,40 @@ int jqc_dft_ao_screen(const double* coords_d, int ngrids, const double* basis_d,
 int jqc_dft_eval_ao(const double* coords_d, int ngrids, const double* basis_d, int nbas, int blk0, int nblk,
                     const uint16_t* shell_list_d, const int32_t* row_of_d, const int32_t* nshl_d, const int32_t* nrow_d,
                     const int64_t* row_base_d, int ncomp, int64_t comp_stride, double* ws_d, int32_t* ao_idx_d,
-                    void* stream)
+                    const float* shell_la_d, float* row_la_d, void* stream)
 {
     if (nblk <= 0) return 0;
     hipLaunchKernelGGL(eval_ao_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, coords_d, ngrids, basis_d, nbas,
                        blk0, shell_list_d, row_of_d, nshl_d, nrow_d, (const long long*)row_base_d, ncomp,
-                       (long long)comp_stride, ws_d, ao_idx_d);
+                       (long long)comp_stride, ws_d, ao_idx_d, shell_la_d, row_la_d);
     HIP_OK(hipGetLastError());
     return 0;
 }
 
 int jqc_dft_rho(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                 const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, int ndim, double* rho_d,
-                void* stream)
+                const float* row_la_d, float thr64, float thr32, void* stream)
 {
     if (nblk <= 0) return 0;
     if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
-    hipLaunchKernelGGL(rho_mfma_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
-                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d);
+    if (ndim > 4)
+        hipLaunchKernelGGL((rho_mfma_kernel<1, 4>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32);
+    else
+        hipLaunchKernelGGL((rho_mfma_kernel<4, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32);
     HIP_OK(hipGetLastError());
     return 0;
 }
 
 int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                 const double* ws_d, const int32_t* ao_idx_d, const double* wv_d, int ndim, int nao, double* vmat_d,
-                void* stream)
+                const float* row_la_d, float thr64, float thr32, void* stream)
 {
     if (nblk <= 0) return 0;
     if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
     hipLaunchKernelGGL(vxc_mfma_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
-                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, wv_d, ndim, nao, vmat_d);
+                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, wv_d, ndim, nao, vmat_d, row_la_d, thr64, thr32);
     HIP_OK(hipGetLastError());
     return 0;
 }

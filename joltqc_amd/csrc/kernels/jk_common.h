@@ -111,6 +111,11 @@ __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_r
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v)
 {
-    // lowers to global_atomic_add_f64 (no CAS loop) on gfx950
+    // lowers to global_atomic_add_f64 (no CAS loop) on gfx950.  ATOMIC_AGENT=1: device (agent) scope instead of the
+    // system scope of unsafeAtomicAdd (no sc1 bit): the Fock matrix is read by nobody before the kernel boundary
+#if defined(ATOMIC_AGENT) && ATOMIC_AGENT
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     unsafeAtomicAdd(p, v);
+#endif
 }

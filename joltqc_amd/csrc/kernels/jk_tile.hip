@@ -131,12 +131,34 @@ constexpr int KS_SHIFT = NKS == 1 ? 16 : NKS == 2 ? 15 : NKS == 4 ? 14 : 13;    
 static_assert(NKS == 1 || (TILE_1Q && (NKS == 2 || NKS == 4 || NKS == 8) && NQ <= (1 << KS_SHIFT)),
               "several ket pairs per iteration: lane-per-quartet mode, 16-bit queue entries");
 
+// Timing-only ablations of the lane-per-quartet mode (WRONG results; tools/ablate.py): bit 0 no Rys table gather, bit 1 no
+// LDS atomics (sums kept alive in a register), bit 2 no density reads from LDS, bit 3 no integral evaluation, bit 4 no
+// compute phase at all (staging + screening + flush only)
+#ifndef ABL
+#define ABL 0
+#endif
+#ifndef QIL
+#define QIL 0       // lane-per-quartet mode: 1 = the survivor queue is read with a stride (consecutive lanes take entries of
+                    // different ket slots / far-apart candidates: fewer lanes of one wave instruction on the same LDS Fock
+                    // element) and J_ij, the one tile every quartet of the workgroup shares, is kept in JREP replicas
+#endif
+#ifndef JREP
+#define JREP (QIL ? 4 : 1)
+#endif
+#ifndef CORD
+#define CORD 0      // lane-per-quartet mode: 1 = contraction with every density read of a row issued before the row's LDS atomics
+                    // of the PREVIOUS row (an LDS read queued behind a same-address atomic waits for its serialised lanes)
+#endif
 // Rys root `r` only (same tables and branches as rys_roots in jk_common.h)
 __device__ __forceinline__ void rys_root_one(real x, real theta, real omega, const int r, const real* cheb,
                                              const real* __restrict__ large, real& root, real& weight)
 {
     real tf = 1, stf = 1;
     x *= theta;
+#if ABL & 1
+    root = x * real(1e-3) + real(0.3) * (r + 1); weight = real(0.5) + x * real(1e-4);
+    return;
+#endif
 #if RYS_LR
     {
         const real w2 = omega * omega;
@@ -264,7 +286,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     // per tile pair fill the 256 lanes from several ket pairs; queue entry = candidate id | ket slot << KS_SHIFT
     __shared__ unsigned short s_act[NKS * NQ];  // their candidate ids, appended wave by wave
     __shared__ real sDij[WJ * WI], sDkl[NKS * WL * WK], sDik[NKS * WI * WK], sDil[NKS * WI * WL], sDjk[NKS * WJ * WK], sDjl[NKS * WJ * WL];
-    __shared__ double sJij[WJ * WI], sJkl[NKS * WL * WK], sKik[NKS * WI * WK], sKil[NKS * WI * WL], sKjk[NKS * WJ * WK], sKjl[NKS * WJ * WL];
+    __shared__ double sJij[(TILE_1Q ? JREP : 1) * WJ * WI], sJkl[NKS * WL * WK], sKik[NKS * WI * WK], sKil[NKS * WI * WL], sKjk[NKS * WJ * WK], sKjl[NKS * WJ * WL];
 #if !TILE_1Q
     __shared__ real sT[NBUF * G * NROOTS * 3 * NT2];
 #endif
@@ -333,7 +355,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             for (int u = 0; u < NRYS; u++) rrys[u] = tid + u * TBLOCK < RYS_TAB ? rys_cheb[tid + u * TBLOCK] : real(0);
         }
 #if DO_J
-        for (int n = tid; n < WJ * WI; n += TBLOCK) sJij[n] = 0;
+        for (int n = tid; n < (TILE_1Q ? JREP : 1) * WJ * WI; n += TBLOCK) sJij[n] = 0;
         for (int n = tid; n < NKS * WL * WK; n += TBLOCK) sJkl[n] = 0;
 #endif
 #if DO_K
@@ -523,8 +545,32 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 
 #if TILE_1Q
             // ---------------- one quartet per lane: everything in registers, then LDS Fock tiles
-            for (int q1 = tid; q1 < nact; q1 += TBLOCK) {
+#if ABL & 2
+            double abl_sink = 0;
+#define LDS_ADD(p, v) (abl_sink += (double)(v))
+#else
+#define LDS_ADD(p, v) lds_add(p, v)
+#endif
+#if ABL & 4
+#define DLD(x) real(0.37)
+#else
+#define DLD(x) (x)
+#endif
+#if QIL
+            // strided read: lane l takes entry (l % QS) * qchunk + l / QS, so the QS = 4 neighbours of a lane group come from
+            // four far-apart quarters of the queue (different ket slots when NKS > 1)
+            constexpr int QS = 4;
+            const int qchunk = (nact + QS - 1) / QS;
+            double* const sJij_r = sJij + (lane & (JREP - 1)) * (WJ * WI);
+            for (int q0 = tid; q0 < ((ABL & 16) ? 0 : QS * qchunk); q0 += TBLOCK) {
+                const int q1 = (q0 % QS) * qchunk + q0 / QS;
+                if (q1 >= nact) continue;
                 const int qe = s_act[q1];
+#else
+            double* const sJij_r = sJij;
+            for (int q1 = tid; q1 < ((ABL & 16) ? 0 : nact); q1 += TBLOCK) {
+                const int qe = s_act[q1];
+#endif
                 const int ks = NKS > 1 ? qe >> KS_SHIFT : 0, qd = NKS > 1 ? qe & ((1 << KS_SHIFT) - 1) : qe;
                 const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
                 int kshb = ksh0s[0], lshb = lsh0s[0];
@@ -549,7 +595,11 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 real I[NINT];
 #pragma unroll
                 for (int n = 0; n < NINT; n++) I[n] = 0;
-                for (int kp = 0; kp < npk; kp++)
+#if ABL & 8
+#pragma unroll
+                for (int n = 0; n < NINT; n++) I[n] = fac * (rij[0] + real(n + 1)) * rkl[1];
+#endif
+                for (int kp = 0; kp < ((ABL & 8) ? 0 : npk); kp++)
                 for (int lp = 0; lp < npl; lp++) {
                     const real ckcl = pk[(kp * 3 + lp) * 3], inv_akl = pk[(kp * 3 + lp) * 3 + 1], akl = pk[(kp * 3 + lp) * 3 + 2];
                     const real al_akl = bl[5 + 2 * lp] * inv_akl;
@@ -605,18 +655,102 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 double* sJkl_q = sJkl + ks * (WL * WK); double* sKik_q = sKik + ks * (WI * WK);
                 double* sKil_q = sKil + ks * (WI * WL); double* sKjk_q = sKjk + ks * (WJ * WK);
                 double* sKjl_q = sKjl + ks * (WJ * WL);
+#if CORD
+                {
+                    // ---- contraction, row by row in i: the density reads of row i + 1 are issued BEFORE the LDS atomics of
+                    //      row i (the DS queue is in order: a read queued behind a same-address atomic waits for its lanes)
+                    real jkl[NFK * NFL], dkl[NFK * NFL], kjk[NFJ * NFK], kjl[NFJ * NFL], djk[NFJ * NFK], djl[NFJ * NFL];
+#pragma unroll
+                    for (int k = 0; k < NFK; k++)
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) { jkl[k * NFL + l] = 0; dkl[k * NFL + l] = DO_J ? DLD(sDkl_q[(lA + l) * WK + kA + k]) : real(0); }
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) { kjk[j * NFK + k] = 0; djk[j * NFK + k] = DO_K ? DLD(sDjk_q[(jA + j) * WK + kA + k]) : real(0); }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) { kjl[j * NFL + l] = 0; djl[j * NFL + l] = DO_K ? DLD(sDjl_q[(jA + j) * WL + lA + l]) : real(0); }
+                    }
+                    real dij_n[NFJ], dik_n[NFK], dil_n[NFL];
+                    auto load_row = [&](const int i) {
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) dij_n[j] = DO_J ? DLD(sDij[(jA + j) * WI + iA + i]) : real(0);
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) dik_n[k] = DO_K ? DLD(sDik_q[(iA + i) * WK + kA + k]) : real(0);
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) dil_n[l] = DO_K ? DLD(sDil_q[(iA + i) * WL + lA + l]) : real(0);
+                    };
+                    load_row(0);
+#pragma unroll
+                    for (int i = 0; i < NFI; i++) {
+                        real dij[NFJ], dik[NFK], dil[NFL], sij[NFJ], kik[NFK], kil[NFL];
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) { dij[j] = dij_n[j]; sij[j] = 0; }
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) { dik[k] = dik_n[k]; kik[k] = 0; }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) { dil[l] = dil_n[l]; kil[l] = 0; }
+                        if (i + 1 < NFI) load_row(i + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                            for (int k = 0; k < NFK; k++)
+#pragma unroll
+                                for (int l = 0; l < NFL; l++) {
+                                    const real v = I[((i * NFJ + j) * NFK + k) * NFL + l];
+#if DO_J
+                                    sij[j] += v * dkl[k * NFL + l];
+                                    jkl[k * NFL + l] += v * dij[j];
+#endif
+#if DO_K
+                                    kik[k] += v * djl[j * NFL + l];
+                                    kil[l] += v * djk[j * NFK + k];
+                                    kjk[j * NFK + k] += v * dil[l];
+                                    kjl[j * NFL + l] += v * dik[k];
+#endif
+                                }
+                        __builtin_amdgcn_sched_barrier(0);
+#if DO_J
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) LDS_ADD(&sJij_r[(jA + j) * WI + iA + i], (double)sij[j]);
+#endif
+#if DO_K
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) LDS_ADD(&sKik_q[(iA + i) * WK + kA + k], (double)kik[k]);
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sKil_q[(iA + i) * WL + lA + l], (double)kil[l]);
+#endif
+                    }
+#if DO_J
+#pragma unroll
+                    for (int k = 0; k < NFK; k++)
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sJkl_q[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
+#endif
+#if DO_K
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) LDS_ADD(&sKjk_q[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sKjl_q[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
+                    }
+#endif
+                }
+#else
 #if DO_J
                 {
                     real jkl[NFK * NFL], dkl[NFK * NFL];
 #pragma unroll
                     for (int k = 0; k < NFK; k++)
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) { jkl[k * NFL + l] = 0; dkl[k * NFL + l] = sDkl_q[(lA + l) * WK + kA + k]; }
+                        for (int l = 0; l < NFL; l++) { jkl[k * NFL + l] = 0; dkl[k * NFL + l] = DLD(sDkl_q[(lA + l) * WK + kA + k]); }
 #pragma unroll
                     for (int i = 0; i < NFI; i++)
 #pragma unroll
                         for (int j = 0; j < NFJ; j++) {
-                            const real dij = sDij[(jA + j) * WI + iA + i];
+                            const real dij = DLD(sDij[(jA + j) * WI + iA + i]);
                             real s = 0;
 #pragma unroll
                             for (int n = 0; n < NFK * NFL; n++) {
@@ -624,12 +758,12 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                 s += v * dkl[n];
                                 jkl[n] += v * dij;
                             }
-                            lds_add(&sJij[(jA + j) * WI + iA + i], (double)s);
+                            LDS_ADD(&sJij_r[(jA + j) * WI + iA + i], (double)s);
                         }
 #pragma unroll
                     for (int k = 0; k < NFK; k++)
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) lds_add(&sJkl_q[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sJkl_q[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
                 }
 #endif
 #if DO_K
@@ -638,17 +772,17 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma unroll
                     for (int j = 0; j < NFJ; j++) {
 #pragma unroll
-                        for (int k = 0; k < NFK; k++) { kjk[j * NFK + k] = 0; djk[j * NFK + k] = sDjk_q[(jA + j) * WK + kA + k]; }
+                        for (int k = 0; k < NFK; k++) { kjk[j * NFK + k] = 0; djk[j * NFK + k] = DLD(sDjk_q[(jA + j) * WK + kA + k]); }
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) { kjl[j * NFL + l] = 0; djl[j * NFL + l] = sDjl_q[(jA + j) * WL + lA + l]; }
+                        for (int l = 0; l < NFL; l++) { kjl[j * NFL + l] = 0; djl[j * NFL + l] = DLD(sDjl_q[(jA + j) * WL + lA + l]); }
                     }
 #pragma unroll
                     for (int i = 0; i < NFI; i++) {
                         real kik[NFK], kil[NFL], dik[NFK], dil[NFL];
 #pragma unroll
-                        for (int k = 0; k < NFK; k++) { kik[k] = 0; dik[k] = sDik_q[(iA + i) * WK + kA + k]; }
+                        for (int k = 0; k < NFK; k++) { kik[k] = 0; dik[k] = DLD(sDik_q[(iA + i) * WK + kA + k]); }
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) { kil[l] = 0; dil[l] = sDil_q[(iA + i) * WL + lA + l]; }
+                        for (int l = 0; l < NFL; l++) { kil[l] = 0; dil[l] = DLD(sDil_q[(iA + i) * WL + lA + l]); }
 #pragma unroll
                         for (int j = 0; j < NFJ; j++)
 #pragma unroll
@@ -662,20 +796,24 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                     kjl[j * NFL + l] += v * dik[k];
                                 }
 #pragma unroll
-                        for (int k = 0; k < NFK; k++) lds_add(&sKik_q[(iA + i) * WK + kA + k], (double)kik[k]);
+                        for (int k = 0; k < NFK; k++) LDS_ADD(&sKik_q[(iA + i) * WK + kA + k], (double)kik[k]);
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) lds_add(&sKil_q[(iA + i) * WL + lA + l], (double)kil[l]);
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sKil_q[(iA + i) * WL + lA + l], (double)kil[l]);
                     }
 #pragma unroll
                     for (int j = 0; j < NFJ; j++) {
 #pragma unroll
-                        for (int k = 0; k < NFK; k++) lds_add(&sKjk_q[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
+                        for (int k = 0; k < NFK; k++) LDS_ADD(&sKjk_q[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
 #pragma unroll
-                        for (int l = 0; l < NFL; l++) lds_add(&sKjl_q[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sKjl_q[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
                     }
                 }
 #endif
-            }
+            #endif  // CORD
+}
+#if ABL & 2
+            if (abl_sink == 1.2345e300) sJij[0] = abl_sink;
+#endif
 #else   // ---------------- row-lane mode
             const int per = (nact + G - 1) / G;
             const int ncomb = npk * npl * npi * npj;
@@ -1129,7 +1267,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             const size_t nao2 = (size_t)nao * nao;
             double* __restrict__ vj = kf->vj;
 #endif
-            flush_tile(sJij, vj + idm * nao2, nao, j0, i0, WJ, WI, tid);   // J_ij: summed over the whole ket chunk
+            // J_ij: summed over the whole ket chunk (lane-per-quartet mode: JREP replicas)
+            for (int rep = 0; rep < (TILE_1Q ? JREP : 1); rep++)
+                flush_tile(sJij + rep * (WJ * WI), vj + idm * nao2, nao, j0, i0, WJ, WI, tid);
         }
 #endif
         STAMP(9);

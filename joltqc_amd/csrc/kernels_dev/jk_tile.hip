@@ -137,6 +137,26 @@ static_assert(NKS == 1 || (TILE_1Q && (NKS == 2 || NKS == 4 || NKS == 8) && NQ <
 #ifndef ABL
 #define ABL 0
 #endif
+#ifndef QIL
+#define QIL 0       // lane-per-quartet mode: 1 = the survivor queue is read with a stride (consecutive lanes take entries of
+                    // different ket slots / far-apart candidates: fewer lanes of one wave instruction on the same LDS Fock
+                    // element) and J_ij, the one tile every quartet of the workgroup shares, is kept in JREP replicas
+#endif
+#ifndef JREP
+#define JREP (QIL ? 4 : 1)
+#endif
+#ifndef RYS_SPLIT
+#define RYS_SPLIT 0
+#endif
+#ifndef CTWO
+#define CTWO 0      // lane-per-quartet mode: 1 = contraction in two sweeps over the integral block -- first the outputs indexed by
+                    // the bra component i (J_ij, K_ik, K_il: emitted row by row), then the three accumulated over i (J_kl, K_jk,
+                    // K_jl) -- so that only half of the density values and accumulators are live at a time (registers)
+#endif
+#ifndef CORD
+#define CORD 0      // lane-per-quartet mode: 1 = contraction with every density read of a row issued before the row's LDS atomics
+                    // of the PREVIOUS row (an LDS read queued behind a same-address atomic waits for its serialised lanes)
+#endif
 // Rys root `r` only (same tables and branches as rys_roots in jk_common.h)
 __device__ __forceinline__ void rys_root_one(real x, real theta, real omega, const int r, const real* cheb,
                                              const real* __restrict__ large, real& root, real& weight)
@@ -165,6 +185,22 @@ __device__ __forceinline__ void rys_root_one(real x, real theta, real omega, con
     const real u = (x - real(2.5) * it) * real(0.8) - real(1);
     const real u2 = u + u;
     const real* c = cheb + (it * NROOTS + r) * (NCOEF * 2);
+#if RYS_SPLIT
+    // root and weight polynomials one after the other: 14 coefficients in flight instead of 28 (register pressure)
+    {
+        real b1 = 0, b2 = 0;
+#pragma unroll
+        for (int k = NCOEF - 1; k >= 1; k--) { const real t = c[2 * k] + u2 * b1 - b2; b2 = b1; b1 = t; }
+        root = (c[0] + u * b1 - b2) * tf;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        real b1 = 0, b2 = 0;
+#pragma unroll
+        for (int k = NCOEF - 1; k >= 1; k--) { const real t = c[2 * k + 1] + u2 * b1 - b2; b2 = b1; b1 = t; }
+        weight = (c[1] + u * b1 - b2) * stf;
+    }
+#else
     real br1 = 0, br2 = 0, bw1 = 0, bw2 = 0;
 #pragma unroll
     for (int k = NCOEF - 1; k >= 1; k--) {
@@ -173,6 +209,7 @@ __device__ __forceinline__ void rys_root_one(real x, real theta, real omega, con
     }
     root = (c[0] + u * br1 - br2) * tf;
     weight = (c[1] + u * bw1 - bw2) * stf;
+#endif
 }
 
 // Staging is split into "issue every global load" and "write LDS": all loads of a workgroup's staging step are in
@@ -274,7 +311,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     // per tile pair fill the 256 lanes from several ket pairs; queue entry = candidate id | ket slot << KS_SHIFT
     __shared__ unsigned short s_act[NKS * NQ];  // their candidate ids, appended wave by wave
     __shared__ real sDij[WJ * WI], sDkl[NKS * WL * WK], sDik[NKS * WI * WK], sDil[NKS * WI * WL], sDjk[NKS * WJ * WK], sDjl[NKS * WJ * WL];
-    __shared__ double sJij[WJ * WI], sJkl[NKS * WL * WK], sKik[NKS * WI * WK], sKil[NKS * WI * WL], sKjk[NKS * WJ * WK], sKjl[NKS * WJ * WL];
+    __shared__ double sJij[(TILE_1Q ? JREP : 1) * WJ * WI], sJkl[NKS * WL * WK], sKik[NKS * WI * WK], sKil[NKS * WI * WL], sKjk[NKS * WJ * WK], sKjl[NKS * WJ * WL];
 #if !TILE_1Q
     __shared__ real sT[NBUF * G * NROOTS * 3 * NT2];
 #endif
@@ -343,7 +380,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             for (int u = 0; u < NRYS; u++) rrys[u] = tid + u * TBLOCK < RYS_TAB ? rys_cheb[tid + u * TBLOCK] : real(0);
         }
 #if DO_J
-        for (int n = tid; n < WJ * WI; n += TBLOCK) sJij[n] = 0;
+        for (int n = tid; n < (TILE_1Q ? JREP : 1) * WJ * WI; n += TBLOCK) sJij[n] = 0;
         for (int n = tid; n < NKS * WL * WK; n += TBLOCK) sJkl[n] = 0;
 #endif
 #if DO_K
@@ -544,8 +581,27 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #else
 #define DLD(x) (x)
 #endif
+#if QIL
+            // strided read: lane l takes entry (l % QS) * qchunk + l / QS, so the QS = 4 neighbours of a lane group come from
+            // four far-apart quarters of the queue (different ket slots when NKS > 1)
+            constexpr int QS = 4;
+            const int qchunk = (nact + QS - 1) / QS;
+            double* const sJij_r = sJij + (lane & (JREP - 1)) * (WJ * WI);
+            for (int q0 = tid; q0 < ((ABL & 16) ? 0 : QS * qchunk); q0 += TBLOCK) {
+                const int q1 = (q0 % QS) * qchunk + q0 / QS;
+                if (q1 >= nact) continue;
+                const int qe = s_act[q1];
+#else
+            double* const sJij_r = sJij;
             for (int q1 = tid; q1 < ((ABL & 16) ? 0 : nact); q1 += TBLOCK) {
                 const int qe = s_act[q1];
+#endif
+#if STAMPS
+                // (diagnostic) slot 13: active lanes of wave 0 summed over its batches; slot 10: time from the end of the previous
+                // batch to here (queue read, loop control)
+                if (tid == 0) st_acc[13] += __popcll(__ballot(true));
+                STAMP(10);
+#endif
                 const int ks = NKS > 1 ? qe >> KS_SHIFT : 0, qd = NKS > 1 ? qe & ((1 << KS_SHIFT) - 1) : qe;
                 const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
                 int kshb = ksh0s[0], lshb = lsh0s[0];
@@ -622,6 +678,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         }
                     }
                 }
+                STAMP(11);          // (diagnostic) integral evaluation of this batch
                 const int iA = a * NFI, jA = b * NFJ, kA = c * NFK, lA = d * NFL;
                 // ket-slot views of the ket-dependent tiles
                 const real* sDkl_q = sDkl + ks * (WL * WK); const real* sDik_q = sDik + ks * (WI * WK);
@@ -630,6 +687,194 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 double* sJkl_q = sJkl + ks * (WL * WK); double* sKik_q = sKik + ks * (WI * WK);
                 double* sKil_q = sKil + ks * (WI * WL); double* sKjk_q = sKjk + ks * (WJ * WK);
                 double* sKjl_q = sKjl + ks * (WJ * WL);
+#if CTWO
+                {
+                    // ---- sweep 1: outputs of row i (J_ij, K_ik, K_il); live: D_kl, D_jl, D_jk
+                    {
+                        real dkl[NFK * NFL], djk[NFJ * NFK], djl[NFJ * NFL];
+#pragma unroll
+                        for (int k = 0; k < NFK; k++)
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) dkl[k * NFL + l] = DO_J ? DLD(sDkl_q[(lA + l) * WK + kA + k]) : real(0);
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) djk[j * NFK + k] = DO_K ? DLD(sDjk_q[(jA + j) * WK + kA + k]) : real(0);
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) djl[j * NFL + l] = DO_K ? DLD(sDjl_q[(jA + j) * WL + lA + l]) : real(0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NFI; i++) {
+                            real sij[NFJ], kik[NFK], kil[NFL];
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++) sij[j] = 0;
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) kik[k] = 0;
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) kil[l] = 0;
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                                for (int k = 0; k < NFK; k++)
+#pragma unroll
+                                    for (int l = 0; l < NFL; l++) {
+                                        const real v = I[((i * NFJ + j) * NFK + k) * NFL + l];
+#if DO_J
+                                        sij[j] += v * dkl[k * NFL + l];
+#endif
+#if DO_K
+                                        kik[k] += v * djl[j * NFL + l];
+                                        kil[l] += v * djk[j * NFK + k];
+#endif
+                                    }
+#if DO_J
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++) LDS_ADD(&sJij_r[(jA + j) * WI + iA + i], (double)sij[j]);
+#endif
+#if DO_K
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) LDS_ADD(&sKik_q[(iA + i) * WK + kA + k], (double)kik[k]);
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) LDS_ADD(&sKil_q[(iA + i) * WL + lA + l], (double)kil[l]);
+#endif
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- sweep 2: outputs accumulated over i (J_kl, K_jk, K_jl); live: the accumulators and one row of D_ij, D_ik, D_il
+                    {
+                        real jkl[NFK * NFL], kjk[NFJ * NFK], kjl[NFJ * NFL];
+#pragma unroll
+                        for (int n = 0; n < NFK * NFL; n++) jkl[n] = 0;
+#pragma unroll
+                        for (int n = 0; n < NFJ * NFK; n++) kjk[n] = 0;
+#pragma unroll
+                        for (int n = 0; n < NFJ * NFL; n++) kjl[n] = 0;
+#pragma unroll
+                        for (int i = 0; i < NFI; i++) {
+                            real dij[NFJ], dik[NFK], dil[NFL];
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++) dij[j] = DO_J ? DLD(sDij[(jA + j) * WI + iA + i]) : real(0);
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) dik[k] = DO_K ? DLD(sDik_q[(iA + i) * WK + kA + k]) : real(0);
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) dil[l] = DO_K ? DLD(sDil_q[(iA + i) * WL + lA + l]) : real(0);
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                                for (int k = 0; k < NFK; k++)
+#pragma unroll
+                                    for (int l = 0; l < NFL; l++) {
+                                        const real v = I[((i * NFJ + j) * NFK + k) * NFL + l];
+#if DO_J
+                                        jkl[k * NFL + l] += v * dij[j];
+#endif
+#if DO_K
+                                        kjk[j * NFK + k] += v * dil[l];
+                                        kjl[j * NFL + l] += v * dik[k];
+#endif
+                                    }
+                        }
+#if DO_J
+#pragma unroll
+                        for (int k = 0; k < NFK; k++)
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) LDS_ADD(&sJkl_q[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
+#endif
+#if DO_K
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) LDS_ADD(&sKjk_q[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) LDS_ADD(&sKjl_q[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
+                        }
+#endif
+                    }
+                }
+#elif CORD
+                {
+                    // ---- contraction, row by row in i: the density reads of row i + 1 are issued BEFORE the LDS atomics of
+                    //      row i (the DS queue is in order: a read queued behind a same-address atomic waits for its lanes)
+                    real jkl[NFK * NFL], dkl[NFK * NFL], kjk[NFJ * NFK], kjl[NFJ * NFL], djk[NFJ * NFK], djl[NFJ * NFL];
+#pragma unroll
+                    for (int k = 0; k < NFK; k++)
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) { jkl[k * NFL + l] = 0; dkl[k * NFL + l] = DO_J ? DLD(sDkl_q[(lA + l) * WK + kA + k]) : real(0); }
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) { kjk[j * NFK + k] = 0; djk[j * NFK + k] = DO_K ? DLD(sDjk_q[(jA + j) * WK + kA + k]) : real(0); }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) { kjl[j * NFL + l] = 0; djl[j * NFL + l] = DO_K ? DLD(sDjl_q[(jA + j) * WL + lA + l]) : real(0); }
+                    }
+                    real dij_n[NFJ], dik_n[NFK], dil_n[NFL];
+                    auto load_row = [&](const int i) {
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) dij_n[j] = DO_J ? DLD(sDij[(jA + j) * WI + iA + i]) : real(0);
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) dik_n[k] = DO_K ? DLD(sDik_q[(iA + i) * WK + kA + k]) : real(0);
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) dil_n[l] = DO_K ? DLD(sDil_q[(iA + i) * WL + lA + l]) : real(0);
+                    };
+                    load_row(0);
+#pragma unroll
+                    for (int i = 0; i < NFI; i++) {
+                        real dij[NFJ], dik[NFK], dil[NFL], sij[NFJ], kik[NFK], kil[NFL];
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) { dij[j] = dij_n[j]; sij[j] = 0; }
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) { dik[k] = dik_n[k]; kik[k] = 0; }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) { dil[l] = dil_n[l]; kil[l] = 0; }
+                        if (i + 1 < NFI) load_row(i + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                            for (int k = 0; k < NFK; k++)
+#pragma unroll
+                                for (int l = 0; l < NFL; l++) {
+                                    const real v = I[((i * NFJ + j) * NFK + k) * NFL + l];
+#if DO_J
+                                    sij[j] += v * dkl[k * NFL + l];
+                                    jkl[k * NFL + l] += v * dij[j];
+#endif
+#if DO_K
+                                    kik[k] += v * djl[j * NFL + l];
+                                    kil[l] += v * djk[j * NFK + k];
+                                    kjk[j * NFK + k] += v * dil[l];
+                                    kjl[j * NFL + l] += v * dik[k];
+#endif
+                                }
+                        __builtin_amdgcn_sched_barrier(0);
+#if DO_J
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) LDS_ADD(&sJij_r[(jA + j) * WI + iA + i], (double)sij[j]);
+#endif
+#if DO_K
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) LDS_ADD(&sKik_q[(iA + i) * WK + kA + k], (double)kik[k]);
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sKil_q[(iA + i) * WL + lA + l], (double)kil[l]);
+#endif
+                    }
+#if DO_J
+#pragma unroll
+                    for (int k = 0; k < NFK; k++)
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sJkl_q[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
+#endif
+#if DO_K
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) LDS_ADD(&sKjk_q[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) LDS_ADD(&sKjl_q[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
+                    }
+#endif
+                }
+#else
 #if DO_J
                 {
                     real jkl[NFK * NFL], dkl[NFK * NFL];
@@ -649,7 +894,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                 s += v * dkl[n];
                                 jkl[n] += v * dij;
                             }
-                            LDS_ADD(&sJij[(jA + j) * WI + iA + i], (double)s);
+                            LDS_ADD(&sJij_r[(jA + j) * WI + iA + i], (double)s);
                         }
 #pragma unroll
                     for (int k = 0; k < NFK; k++)
@@ -700,7 +945,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     }
                 }
 #endif
-            }
+            #endif  // CORD
+                STAMP(12);          // (diagnostic) contraction + LDS atomics of this batch
+}
 #if ABL & 2
             if (abl_sink == 1.2345e300) sJij[0] = abl_sink;
 #endif
@@ -1157,7 +1404,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             const size_t nao2 = (size_t)nao * nao;
             double* __restrict__ vj = kf->vj;
 #endif
-            flush_tile(sJij, vj + idm * nao2, nao, j0, i0, WJ, WI, tid);   // J_ij: summed over the whole ket chunk
+            // J_ij: summed over the whole ket chunk (lane-per-quartet mode: JREP replicas)
+            for (int rep = 0; rep < (TILE_1Q ? JREP : 1); rep++)
+                flush_tile(sJij + rep * (WJ * WI), vj + idm * nao2, nao, j0, i0, WJ, WI, tid);
         }
 #endif
         STAMP(9);

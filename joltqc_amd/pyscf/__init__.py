@@ -27,6 +27,9 @@ def get_default_config() -> Dict[str, Any]:
         # True: share the work over the ranks of the initialised torch.distributed group (joltqc_amd/pyscf/parallel.py);
         # not in the reference, which drives one device
         "parallel": False,
+        # True: mf.get_hcore / mf.get_ovlp from the device kernels (joltqc_amd/pyscf/int1e.py) instead of the object's own
+        # (PySCF: libcint on the CPU); objects with ECPs keep their own
+        "int1e": False,
     }
 
 
@@ -125,6 +128,14 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
                 obj.get_k = lambda *a, **k: get_jk(*a, with_j=False, with_k=True, **k)[1]
         if _is(obj, "RHF") and not _is(obj, "RKS"):
             obj.get_veff = MethodType(_jk.generate_get_veff(), obj)
+
+    if config.get("int1e") and not getattr(obj.mol, "has_ecp", lambda: False)():
+        from . import int1e as _int1e
+        lay1 = BasisLayout.from_mol(obj.mol, alignment=1)
+        # (bound like the originals: mf.get_hcore(mol=None), mf.get_ovlp(mol=None))
+        hc, ov = _int1e.generate_get_hcore(lay1, numpy_boundary), _int1e.generate_get_ovlp(lay1, numpy_boundary)
+        obj.get_hcore = lambda mol=None: hc(None)
+        obj.get_ovlp = lambda mol=None: ov(None)
 
     if _is(obj, "RKS"):                      # after the J/K closures: the RKS get_veff calls them
         from . import rks as _rks

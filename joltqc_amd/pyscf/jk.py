@@ -428,9 +428,12 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
     state = {"pairs": {}, "tiles": {}, "queue": None, "stats": {}, "probe": None, "plan_cache": {}, "streams": None,
              "nstreams": N_STREAMS}
 
-    def get_jk(mol_ref=None, dm=None, hermi=0, vhfopt=None, with_j=True, with_k=True, omega=None, verbose=None):
+    def get_jk(mol_ref=None, dm=None, hermi=0, vhfopt=None, with_j=True, with_k=True, omega=None, verbose=None,
+               _classes=None):
         """Compute J, K; compatible with ``pyscf.scf.hf.get_jk`` / the reference closure (jk.py:109-118).
-        ``mol_ref`` is ignored in favour of the layout captured at ``apply`` time (jk.py:123)."""
+        ``mol_ref`` is ignored in favour of the layout captured at ``apply`` time (jk.py:123).
+        ``_classes`` (internal): predicate on the angular class (li, lj, lk, ll); classes it rejects are left out
+        (the pair-based backend evaluates those itself, joltqc_amd/pyscf/jk_pair.py)."""
         assert with_j or with_k
         if omega is not None:
             assert omega >= 0.0, "short ranged J/K not supported"
@@ -597,7 +600,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                 only = __import__('os').environ.get("JQC_ONLY_CLASS")
                 for n, ang in enumerate(order):
                     tab, nblk, _, _ = tplans[ang]
-                    if only and "%d%d%d%d" % tuple(ang) not in only.split(","):
+                    if (only and "%d%d%d%d" % tuple(ang) not in only.split(",")) or (_classes is not None and not _classes(ang)):
                         row += tab.shape[0]
                         continue
                     idx_p = entry["index_d"].data_ptr() + entry["index_off"][ang] * 4
@@ -638,7 +641,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                 state["stats"]["tile_rows"] = entry["row_meta"]
 
         # ---------------- queue path (one quartet per lane) for the classes routed to it
-        want_q = (lambda ang: not is_tile(ang)) if tiled_layout else None
+        want_q = (lambda ang: not is_tile(ang) and (_classes is None or _classes(ang))) if tiled_layout else _classes
         need_queue = (not tiled_layout) or any(
             not is_tile((int(a), int(b), int(c), int(d)))
             for a in set(layout.angs) for b in set(layout.angs) for c in set(layout.angs) for d in set(layout.angs)

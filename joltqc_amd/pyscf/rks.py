@@ -11,8 +11,9 @@ into an HBM workspace and contracted with FP64 MFMA (``C = D_bb AO_b`` for the d
 ``V_bb = AO_b X_b^T`` for the potential).  XC functional evaluation itself stays with the caller's
 ``ni.eval_xc_eff`` (libxc, third party), exactly as in the reference (:341).
 
-Gap kept explicit: the reference's FP32 window (contributions between cutoff_fp32 and cutoff_fp64
-evaluated in single precision) is evaluated in FP64 here, i.e. at least as accurately.
+Precision windows as in the reference (rks.py:446-493): the block's AO rows are sorted by their log estimate, so the
+AO pairs above ``cutoff_fp64`` form a corner of the block's pair matrix that goes through the FP64 MFMA, the band down to
+``cutoff_fp32`` through the FP32 MFMA (twice the rate), the rest is skipped.
 """
 import math
 
@@ -76,13 +77,15 @@ class _GridCache:
             row_of = torch.empty((nblk, nbas), dtype=torch.int32, device=dev)
             nshl = torch.empty(nblk, dtype=torch.int32, device=dev)
             nrow = torch.empty(nblk, dtype=torch.int32, device=dev)
+            shell_la = torch.empty((nblk, nbas), dtype=torch.float32, device=dev)
             _lib.check(L.jqc_dft_ao_screen(soa.data_ptr(), self.ngrids_pad, layout.basis_data_fp64["packed"].data_ptr(),
                                            layout.device_ao_loc().data_ptr(), nbas, float(bucket), shell_list.data_ptr(),
-                                           row_of.data_ptr(), nshl.data_ptr(), nrow.data_ptr(), _lib.stream_ptr()))
+                                           row_of.data_ptr(), nshl.data_ptr(), nrow.data_ptr(), shell_la.data_ptr(),
+                                           _lib.stream_ptr()))
             nrow_h = nrow.cpu().numpy().astype(np.int64)
             if len(self.sparsity) > 16:
                 self.sparsity.clear()
-            self.sparsity[bucket] = (shell_list, row_of, nshl, nrow, nrow_h)
+            self.sparsity[bucket] = (shell_list, row_of, nshl, nrow, nrow_h, shell_la)
         return self.sparsity[bucket]
 
 
@@ -112,6 +115,10 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
     gcache = _GridCache()
     state = {"ws": None, "stats": {}}
     log_ao_cutoff = math.log(min(ao_cutoff, cutoff_fp32))
+    # precision windows of the AO-pair contributions (reference rks.py:446-493): >= cutoff_fp64 in FP64, [cutoff_fp32,
+    # cutoff_fp64) in FP32, below cutoff_fp32 dropped
+    log_cut32 = math.log(cutoff_fp32)
+    log_cut64 = math.log(max(cutoff_fp64, cutoff_fp32))
 
     def _workspace(dev, rows, ncomp):
         need = rows * NG * ncomp
@@ -123,7 +130,7 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
         dev = _lib.require_gpu()
         L = _lib.lib()
         soa = gcache.coords(grids, dev)
-        shell_list, row_of, nshl, nrow, nrow_h = gcache.shells(layout, soa, log_cutoff)
+        shell_list, row_of, nshl, nrow, nrow_h, shell_la = gcache.shells(layout, soa, log_cutoff)
         basis = layout.basis_data_fp64["packed"]
         stream = _lib.stream_ptr()
         rows_total = 0
@@ -137,12 +144,13 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
             ws = _workspace(dev, rows, ncomp_ao)
             base_d = torch.from_numpy(base).to(dev)
             ao_idx = torch.empty(rows, dtype=torch.int32, device=dev)
+            row_la = torch.empty(rows, dtype=torch.float32, device=dev)
             comp_stride = rows * NG
             _lib.check(L.jqc_dft_eval_ao(soa.data_ptr(), gcache.ngrids_pad, basis.data_ptr(), layout.nbasis, blk0, nblk,
                                          shell_list.data_ptr(), row_of.data_ptr(), nshl.data_ptr(), nrow.data_ptr(),
                                          base_d.data_ptr(), ncomp_ao, comp_stride, ws.data_ptr(), ao_idx.data_ptr(),
-                                         stream))
-            body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, stream)
+                                         shell_la.data_ptr(), row_la.data_ptr(), stream))
+            body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, row_la, stream)
             rows_total += int(rows)
         state["stats"]["ao_rows"] = rows_total
         state["stats"]["blocks"] = len(nrow_h)
@@ -160,9 +168,12 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
         soa = gcache.coords(grids, dev)
         rho = torch.zeros((ndim, gcache.ngrids_pad), dtype=torch.float64, device=dev)
 
-        def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, stream):
+        def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, row_la, stream):
+            # AO pairs with log_ao_a + log_ao_b + log|D|max in [log cutoff_fp32, log cutoff_fp64) go through the FP32 MFMA,
+            # above through the FP64 one, below nowhere (reference rks.py:446-493, eval_rho.cu:93-106)
             _lib.check(L.jqc_dft_rho(blk0, nblk, gcache.ngrids_pad, nrow.data_ptr(), base_d.data_ptr(), comp_stride,
-                                     ws.data_ptr(), ao_idx.data_ptr(), d.data_ptr(), nao, ndim, rho.data_ptr(), stream))
+                                     ws.data_ptr(), ao_idx.data_ptr(), d.data_ptr(), nao, ndim, rho.data_ptr(),
+                                     row_la.data_ptr(), log_cut64 - log_dm, log_cut32 - log_dm, stream))
         _run(grids, 1 if ndim == 1 else 4, log_ao_cutoff - log_dm, body)
         if nranks > 1:
             import torch.distributed as dist
@@ -186,9 +197,10 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
         log_wv_max = math.log((float(w.abs().max().item()) + 1e-300) * ngrids_per_atom)   # reference :548-551
         vmat = torch.zeros((nao, nao), dtype=torch.float64, device=dev)
 
-        def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, stream):
+        def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, row_la, stream):
             _lib.check(L.jqc_dft_vxc(blk0, nblk, gcache.ngrids_pad, nrow.data_ptr(), base_d.data_ptr(), comp_stride,
-                                     ws.data_ptr(), ao_idx.data_ptr(), w.data_ptr(), ndim, nao, vmat.data_ptr(), stream))
+                                     ws.data_ptr(), ao_idx.data_ptr(), w.data_ptr(), ndim, nao, vmat.data_ptr(),
+                                     row_la.data_ptr(), log_cut64 - log_wv_max, log_cut32 - log_wv_max, stream))
         _run(grids, 1 if ndim == 1 else 4, log_ao_cutoff - log_wv_max, body)
         if nranks > 1:
             import torch.distributed as dist

@@ -213,8 +213,11 @@ void jqc_oracle_eri_block(const double *basis, int ish, int jsh, int ksh, int ls
  *   vk[i*nao + k] += sum_jl (ij|kl) dm[j*nao + l]      vk[i*nao + l] += sum_jk (ij|kl) dm[j*nao + k]
  *   vk[j*nao + k] += sum_il (ij|kl) dm[i*nao + l]      vk[j*nao + l] += sum_ik (ij|kl) dm[i*nao + k]
  */
+/* shared != 0: vj / vk are shared by several OpenMP threads, every update is an atomic add (large matrices, where
+ * one private copy per thread would not fit) */
+#define ACC(p, v) do { if (shared) { _Pragma("omp atomic") (p) += (v); } else (p) += (v); } while (0)
 static void jk_one_quartet(int nao, const double *basis, int n_dm, const double *dm, double *vj, double *vk, double omega,
-                           int ish, int jsh, int ksh, int lsh, int do_j, int do_k, double *blk)
+                           int ish, int jsh, int ksh, int lsh, int do_j, int do_k, double *blk, int shared)
 {
     const long nao2 = (long)nao * nao;
     double fac = PI_FAC;
@@ -240,14 +243,14 @@ static void jk_one_quartet(int nao, const double *basis, int n_dm, const double 
             const double v = *e;
             const int I = i0 + i, Jx = j0 + j, Kx = k0 + k, Lx = l0 + l;
             if (do_j) {
-                J[Kx + (long)Lx * nao] += v * D[I + (long)Jx * nao];
-                J[I + (long)Jx * nao] += v * D[Kx + (long)Lx * nao];
+                ACC(J[Kx + (long)Lx * nao], v * D[I + (long)Jx * nao]);
+                ACC(J[I + (long)Jx * nao], v * D[Kx + (long)Lx * nao]);
             }
             if (do_k) {
-                K[(long)I * nao + Kx] += v * D[(long)Jx * nao + Lx];
-                K[(long)I * nao + Lx] += v * D[(long)Jx * nao + Kx];
-                K[(long)Jx * nao + Kx] += v * D[(long)I * nao + Lx];
-                K[(long)Jx * nao + Lx] += v * D[(long)I * nao + Kx];
+                ACC(K[(long)I * nao + Kx], v * D[(long)Jx * nao + Lx]);
+                ACC(K[(long)I * nao + Lx], v * D[(long)Jx * nao + Kx]);
+                ACC(K[(long)Jx * nao + Kx], v * D[(long)I * nao + Lx]);
+                ACC(K[(long)Jx * nao + Lx], v * D[(long)I * nao + Kx]);
             }
         }
     }
@@ -263,24 +266,29 @@ void jqc_oracle_jk_mt(int nao, const double *basis, int n_dm, const double *dm, 
         double *blk = (double *)malloc(sizeof(double) * NF_MAX * NF_MAX * NF_MAX * NF_MAX);
         for (long t = 0; t < ntasks; t++)
             jk_one_quartet(nao, basis, n_dm, dm, vj, vk, omega, quartets[4 * t], quartets[4 * t + 1], quartets[4 * t + 2],
-                           quartets[4 * t + 3], do_j, do_k, blk);
+                           quartets[4 * t + 3], do_j, do_k, blk, 0);
         free(blk);
         return;
     }
+    /* private accumulators cost nthreads * 2 * nmat doubles: beyond 1 GiB the threads share vj / vk through atomic adds */
+    const int shared = (double)nthreads * 2.0 * (double)nmat * 8.0 > 1073741824.0;
 #pragma omp parallel num_threads(nthreads)
     {
         double *blk = (double *)malloc(sizeof(double) * NF_MAX * NF_MAX * NF_MAX * NF_MAX);
-        double *pj = (double *)calloc(nmat, sizeof(double)), *pk = (double *)calloc(nmat, sizeof(double));
+        double *pj = shared ? vj : (double *)calloc(nmat, sizeof(double)), *pk = shared ? vk : (double *)calloc(nmat, sizeof(double));
 #pragma omp for schedule(dynamic, 256)
         for (long t = 0; t < ntasks; t++)
             jk_one_quartet(nao, basis, n_dm, dm, pj, pk, omega, quartets[4 * t], quartets[4 * t + 1], quartets[4 * t + 2],
-                           quartets[4 * t + 3], do_j, do_k, blk);
+                           quartets[4 * t + 3], do_j, do_k, blk, shared);
+        if (!shared) {
 #pragma omp critical
-        {
-            if (vj) for (long n = 0; n < nmat; n++) vj[n] += pj[n];
-            if (vk) for (long n = 0; n < nmat; n++) vk[n] += pk[n];
+            {
+                if (vj) for (long n = 0; n < nmat; n++) vj[n] += pj[n];
+                if (vk) for (long n = 0; n < nmat; n++) vk[n] += pk[n];
+            }
+            free(pj); free(pk);
         }
-        free(blk); free(pj); free(pk);
+        free(blk);
     }
 }
 
@@ -304,10 +312,11 @@ long jqc_oracle_jk_dense(int nao, const double *basis, int nbas, const unsigned 
     const long nmat = (long)n_dm * nao * nao;
     long total = 0;
     if (nthreads < 1) nthreads = 1;
+    const int shared = nthreads > 1 && (double)nthreads * 2.0 * (double)nmat * 8.0 > 1073741824.0;
 #pragma omp parallel num_threads(nthreads) reduction(+ : total)
     {
         double *blk = (double *)malloc(sizeof(double) * NF_MAX * NF_MAX * NF_MAX * NF_MAX);
-        double *pj = (double *)calloc(nmat, sizeof(double)), *pk = (double *)calloc(nmat, sizeof(double));
+        double *pj = shared ? vj : (double *)calloc(nmat, sizeof(double)), *pk = shared ? vk : (double *)calloc(nmat, sizeof(double));
 #pragma omp for schedule(dynamic, 1)
         for (int i = nbas - 1; i >= 0; i--) {
             if (skip[i]) continue;
@@ -319,18 +328,21 @@ long jqc_oracle_jk_dense(int nao, const double *basis, int nbas, const unsigned 
                     for (int l = 0; l <= k; l++) {
                         if (skip[l] || (long)i * nbas + j < (long)k * nbas + l) continue;
                         if (lq && qij + lq[(long)k * nbas + l] + log_dmax <= log_cut) continue;
-                        jk_one_quartet(nao, basis, n_dm, dm, pj, pk, omega, i, j, k, l, do_j, do_k, blk);
+                        jk_one_quartet(nao, basis, n_dm, dm, pj, pk, omega, i, j, k, l, do_j, do_k, blk, shared);
                         total++;
                     }
                 }
             }
         }
+        if (!shared) {
 #pragma omp critical
-        {
-            if (vj) for (long n = 0; n < nmat; n++) vj[n] += pj[n];
-            if (vk) for (long n = 0; n < nmat; n++) vk[n] += pk[n];
+            {
+                if (vj) for (long n = 0; n < nmat; n++) vj[n] += pj[n];
+                if (vk) for (long n = 0; n < nmat; n++) vk[n] += pk[n];
+            }
+            free(pj); free(pk);
         }
-        free(blk); free(pj); free(pk);
+        free(blk);
     }
     return total;
 }

@@ -53,6 +53,12 @@ class RHF:
     def get_jk(self, mol=None, dm=None, hermi=1, **kw):
         raise RuntimeError("no J/K engine attached: call joltqc_amd.pyscf.apply(mf) (or attach an oracle in tests)")
 
+    def get_j(self, mol=None, dm=None, hermi=1, **kw):
+        return self.get_jk(mol, dm, hermi, with_k=False, **kw)[0]
+
+    def get_k(self, mol=None, dm=None, hermi=1, **kw):
+        return self.get_jk(mol, dm, hermi, with_j=False, **kw)[1]
+
     def get_veff(self, mol=None, dm=None, dm_last=None, vhf_last=None, hermi=1):
         vj, vk = self.get_jk(mol, dm, hermi)
         return vj - 0.5 * vk

@@ -72,6 +72,39 @@ def test_rho_vxc_water_svp_gga_sparse_blocks():
     assert np.abs(v - vref).max() < 1e-8 * np.abs(vref).max()
 
 
+def test_fp32_window_and_pair_cutoff():
+    """Reference precision windows (jqc/pyscf/rks.py:446-493, eval_rho.cu:93-106): AO pairs whose estimate lies in
+    [cutoff_fp32, cutoff_fp64) go through the FP32 MFMA.  With the default DFT cutoffs of apply() (1e-13 / 1e-6) the result
+    must stay within the reference's 1e-7 of the all-FP64 oracle, and must not be bit-identical to the all-FP64 run (the
+    FP32 path really ran)."""
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import rks
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import dft
+    mol = mole.Mole(atom=benzene_like(), basis="def2-svp")
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    grids = Grids(mol, 8192)
+    _, rho64, vxc64 = rks.generate_rks_kernel(lay, cutoff_fp64=1e-13, cutoff_fp32=1e-13)
+    _, rho_m, vxc_m = rks.generate_rks_kernel(lay, cutoff_fp64=1e-6, cutoff_fp32=1e-13)
+    np.random.seed(4)
+    c = np.random.rand(mol.nao, mol.nelectron // 2) - 0.5
+    dm = 2 * c @ c.T
+    wv = np.random.rand(4, 8192)
+    ref_r = dft.eval_rho(lay, grids.coords, dm, "GGA")
+    ref_v = dft.eval_vxc(lay, grids.coords, wv, "GGA")
+    for fn, arg, ref in ((rho64, dm, ref_r), (rho_m, dm, ref_r), (vxc64, wv, ref_v), (vxc_m, wv, ref_v)):
+        got = fn(mol, grids, "GGA", arg).cpu().numpy()
+        assert np.abs(got - ref).max() < 1e-7 * max(1.0, np.abs(ref).max())
+    d_r = np.abs(rho_m(mol, grids, "GGA", dm).cpu().numpy() - rho64(mol, grids, "GGA", dm).cpu().numpy()).max()
+    d_v = np.abs(vxc_m(mol, grids, "GGA", wv).cpu().numpy() - vxc64(mol, grids, "GGA", wv).cpu().numpy()).max()
+    assert 0.0 < d_r < 1e-7 * np.abs(ref_r).max() and 0.0 < d_v < 1e-7 * np.abs(ref_v).max()
+
+
+def benzene_like():
+    from conftest import benzene_atoms
+    return benzene_atoms()
+
+
 def test_vv10_kernel_and_driver():
     from joltqc_amd.pyscf import rks
     from oracle import dft

@@ -20,6 +20,7 @@ def env_for(abl):
     e["JQC_EXTRA_DEFS"] = f"-DABL={abl}"
     e["JQC_ONLY_CLASS"] = ",".join(CLASSES)
     e["JQC_STREAMS"] = "1"
+    e["JQC_TRUST_KERNELS"] = "1"          # wrong by construction: no first-use cross-check
     return e
 
 

@@ -43,6 +43,11 @@ print("kernel, us/launch, hw FP64 flop (64 lanes x (2 FMA + MUL + ADD) wave inst
 for us, k, hw, mf, nq, fetch, write, atom, hit, miss in rows:
     print(f"{k},{us:.1f},{hw:.4g},{mf:.4g},{hw/us/1e6:.2f},{mf/us/1e6:.2f},{nq},{fetch/1e6:.2f},{write/1e6:.2f},"
           f"{(fetch+write)/us/1e3:.1f},{atom:.4g},{hit/(hit+miss) if hit+miss else float('nan'):.3f}")
+# machine-readable copy for bench.py's roofline.traffic (profiles/*pmc_traffic*.json)
+json.dump({k: {"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "us_per_launch": us,
+               "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction of MI355X_MICROARCH.md) and WRITE_SIZE, separate passes"}
+           for us, k, hw, mf, nq, fetch, write, atom, hit, miss in rows if fetch == fetch and write == write},
+          open(f"{root}/pmc_traffic.json", "w"), indent=1)
 tot_us = sum(r[0] for r in rows)
 print(f"TOTAL,{tot_us:.1f},{sum(r[2] for r in rows):.4g},{sum(r[3] for r in rows if r[3]==r[3]):.4g},,,"
       f"{sum(r[4] for r in rows if r[4]==r[4])},{sum(r[5] for r in rows)/1e6:.2f},{sum(r[6] for r in rows)/1e6:.2f}")

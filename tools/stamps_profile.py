@@ -5,6 +5,7 @@ cls = sys.argv[1]
 os.environ["JQC_ONLY_CLASS"] = cls
 os.environ["JQC_EXTRA_DEFS"] = os.environ.get("JQC_EXTRA_DEFS", "") + " -DSTAMPS=1"
 os.environ["JQC_KERNEL_CACHE"] = "/tmp/kc_stamps"
+os.environ["JQC_TRUST_KERNELS"] = "1"
 os.environ.setdefault("JQC_STREAMS", "1")
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,9 +26,19 @@ names = ["lookup", "bra stage", "Dij stage", "ket loads issue", "ket stage store
 n64, _, per = g.quartet_counts()
 print(f"{name} class {cls}: workgroups {nwg}, quartets {n64}, quartets/WG {n64 / nwg:.1f}")
 tot = sum(int(x) for x in st[:14])
-if int(st[10]) + int(st[11]):
+from joltqc_amd.backend import jk as _router
+tile1q = (_router.select_algo(tuple(int(c) for c in cls)) & 0xf) == 2
+lanes = 0
+if tile1q and int(st[11]):
+    # lane-per-quartet mode: slots 10-12 = batch overhead / integral evaluation / contraction + atomics of wave 0, slot 13 = active lanes
+    names += ["  (batch head)", "  (integrals)", "  (contraction)"]
+    lanes = int(st[13]); st[13] = 0
+    st[6] -= st[10] + st[11] + st[12]
+elif int(st[10]) + int(st[11]):
     names += ["  (phase A)", "  (phase B)", "  (step barrier)", "  (contraction)"]
     st[6] -= st[10] + st[11] + st[12] + st[13]      # compute = remainder outside the stamped inner phases
 for k, nm in enumerate(names):
     print(f"  {nm:16s} {int(st[k]) / nwg:10.0f} cycles/WG  {100.0 * int(st[k]) / max(tot, 1):5.1f} %")
 print(f"  total            {tot / nwg:10.0f} cycles/WG")
+if lanes:
+    print(f"  wave 0: {lanes / nwg:.1f} lane-quartets per WG (its share of {n64 / nwg:.1f} quartets/WG over 4 waves)")
