@@ -23,7 +23,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline  the CPU oracle (C restatement of the reference arithmetic, OpenMP over os.cpu_count() host cores) on a
                 bounded sample drawn from the dispatched class histogram of this workload; PySCF's get_jk is used
                 instead when it is importable on the box (it is not in this image).
-  grid_path     rho / vxc (GGA) of the DFT grid path on the same molecule and basis with a synthetic atom-centred grid:
+  grid_path     rho / vxc (GGA) of the DFT grid path on the same molecule and basis with a Becke grid (own generator):
                 grid points x AO pairs per second and the fraction of the FP64 MFMA peak (N = 1 only).
 """
 import argparse
@@ -138,31 +138,31 @@ def committed_traffic(kernel):
 
 
 def grid_leg(mol, nsteps=3):
-    """rho / vxc (GGA) throughput on a synthetic atom-centred grid (the kernels do not care how a grid was generated)."""
+    """rho / vxc (GGA) throughput on a Becke grid; algorithmic flops = 256 (2 m^2 + 8 m) per block of m significant AOs."""
     import torch
     from joltqc_amd.pyscf import rks
     from joltqc_amd.pyscf.basis import BasisLayout
     from joltqc_amd.roofline import FP64_MFMA_PEAK_TFLOPS
     lay = BasisLayout.from_mol(mol, alignment=1)
-    rng = np.random.default_rng(0)
-    at = mol.atom_coords()
-    per = 3072
-    r = np.abs(rng.normal(0, 1.5, (mol.natm, per, 1))) + 0.05
-    u = rng.normal(size=(mol.natm, per, 3)); u /= np.linalg.norm(u, axis=-1, keepdims=True)
-    coords = (at[:, None, :] + r * u).reshape(-1, 3)
-    coords = coords[rks.arg_group_grids(coords)]
+    # Becke grid, 30 radial x (8 x 16) angular points per atom (joltqc_amd/gto/grids.py: grid generation is third party in the
+    # reference), box-sorted and padded to 256 like rks.build_grids does
+    from joltqc_amd.gto.grids import Grids
+    gg = Grids(mol, 30, 8).build()
+    order = rks.arg_group_grids(gg.coords)
+    coords, weights = gg.coords[order], gg.weights[order]
     n = coords.shape[0] // 256 * 256
+    per = coords.shape[0] // mol.natm
 
     class G:
         pass
-    g = G(); g.coords = coords[:n]; g.weights = np.full(n, 1e-3)
+    g = G(); g.coords = coords[:n]; g.weights = weights[:n]
     _, rho_k, vxc_k = rks.generate_rks_kernel(lay)
     np.random.seed(9)
     nocc = max(mol.nelectron // 2, 1)
     c = np.random.rand(mol.nao, nocc) - 0.5
     dm = torch.from_numpy(c @ c.T / nocc).cuda()
     wv = torch.rand((4, n), dtype=torch.float64, device="cuda")
-    out = {"xc": "GGA", "ngrids": n, "nao": mol.nao, "grid": f"synthetic, {per} points per atom, box-sorted"}
+    out = {"xc": "GGA", "ngrids": n, "nao": mol.nao, "grid": f"Becke, {per} points per atom (30 radial x 128 angular), box-sorted"}
     for fn, arg, label in ((rho_k, dm, "rho"), (vxc_k, wv, "vxc")):
         fn(mol, g, "GGA", arg); torch.cuda.synchronize()
         t = time.perf_counter()
@@ -175,6 +175,15 @@ def grid_leg(mol, nsteps=3):
         fl = 2.0 * pairs + 8.0 * 256 * float(m.sum())                # 256 (2 m^2 + 8 m) per block
         out[label] = {"ms": dt * 1e3, "points_x_ao_pairs_per_s": pairs / dt, "tflops": fl / dt / 1e12,
                       "frac_fp64_mfma_peak": fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS, "mean_ao_per_block": float(m.mean())}
+    # the same two calls with the default DFT cutoffs of apply() (cutoff_fp64 = 1e-6: weak AO pairs through the FP32 MFMA)
+    _, rho_m, vxc_m = rks.generate_rks_kernel(lay, cutoff_fp64=1e-6, cutoff_fp32=1e-13)
+    for fn, arg, label in ((rho_m, dm, "rho"), (vxc_m, wv, "vxc")):
+        fn(mol, g, "GGA", arg); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(nsteps):
+            fn(mol, g, "GGA", arg)
+        torch.cuda.synchronize()
+        out[label]["ms_mixed_fp32_window"] = (time.perf_counter() - t) / nsteps * 1e3
     return out
 
 

@@ -145,6 +145,18 @@ static_assert(NKS == 1 || (TILE_1Q && (NKS == 2 || NKS == 4 || NKS == 8) && NQ <
 #ifndef JREP
 #define JREP (QIL ? 4 : 1)
 #endif
+#ifndef STAGE_ALL
+#define STAGE_ALL 0  // 1: issue every global load of every ket slot of an iteration (tiles, prefactors, screening gathers) before
+                     // the first one is used
+#endif
+#ifndef RYS_SPLIT
+#define RYS_SPLIT 0
+#endif
+#ifndef CTWO
+#define CTWO 0      // lane-per-quartet mode: 1 = contraction in two sweeps over the integral block -- first the outputs indexed by
+                    // the bra component i (J_ij, K_ik, K_il: emitted row by row), then the three accumulated over i (J_kl, K_jk,
+                    // K_jl) -- so that only half of the density values and accumulators are live at a time (registers)
+#endif
 #ifndef CORD
 #define CORD 0      // lane-per-quartet mode: 1 = contraction with every density read of a row issued before the row's LDS atomics
                     // of the PREVIOUS row (an LDS read queued behind a same-address atomic waits for its serialised lanes)
@@ -177,6 +189,22 @@ __device__ __forceinline__ void rys_root_one(real x, real theta, real omega, con
     const real u = (x - real(2.5) * it) * real(0.8) - real(1);
     const real u2 = u + u;
     const real* c = cheb + (it * NROOTS + r) * (NCOEF * 2);
+#if RYS_SPLIT
+    // root and weight polynomials one after the other: 14 coefficients in flight instead of 28 (register pressure)
+    {
+        real b1 = 0, b2 = 0;
+#pragma unroll
+        for (int k = NCOEF - 1; k >= 1; k--) { const real t = c[2 * k] + u2 * b1 - b2; b2 = b1; b1 = t; }
+        root = (c[0] + u * b1 - b2) * tf;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        real b1 = 0, b2 = 0;
+#pragma unroll
+        for (int k = NCOEF - 1; k >= 1; k--) { const real t = c[2 * k + 1] + u2 * b1 - b2; b2 = b1; b1 = t; }
+        weight = (c[1] + u * b1 - b2) * stf;
+    }
+#else
     real br1 = 0, br2 = 0, bw1 = 0, bw2 = 0;
 #pragma unroll
     for (int k = NCOEF - 1; k >= 1; k--) {
@@ -185,6 +213,7 @@ __device__ __forceinline__ void rys_root_one(real x, real theta, real omega, con
     }
     root = (c[0] + u * br1 - br2) * tf;
     weight = (c[1] + u * bw1 - bw2) * stf;
+#endif
 }
 
 // Staging is split into "issue every global load" and "write LDS": all loads of a workgroup's staging step are in
@@ -213,6 +242,66 @@ __device__ __forceinline__ void tile_store(real* __restrict__ dst, const TileReg
 }
 
 // add the tile to the global matrix and clear it (the thread that flushes an element is the one that clears it)
+#ifndef FLUSH_UNROLL
+#define FLUSH_UNROLL TILE_1Q   // 1: straight-line flush of a tile (its size is compile-time) instead of a rolled loop.  The compiler
+                         // puts an `s_waitcnt vmcnt(0)` in front of every LDS store that follows a global atomic, i.e. every
+                         // element waits for the previous atomic to complete at L2; unrolled, a tile's LDS reads are issued
+                         // together and its few waits overlap.  Measured on the 112-atom run: -4.7 % over the 30
+                         // lane-per-quartet classes ((dp|ps) -11 %); 2 (every tile read first, all atomics last) costs scratch
+                         // and gains only 1 % (profiles/r02_ab_flush_staging_tile1q_112atoms.txt); row-lane kernels: 1 %, left rolled.
+#endif
+#if FLUSH_UNROLL
+template <int NR, int NC>
+__device__ __forceinline__ void flush_tile_t(double* __restrict__ src, double* __restrict__ out, const int nao,
+                                             const int r0, const int c0, const int tid)
+{
+    constexpr int NU = (NR * NC + TBLOCK - 1) / TBLOCK;
+    double v[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int idx = tid + u * TBLOCK;
+        v[u] = idx < NR * NC ? src[idx] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        const int idx = tid + u * TBLOCK;
+        const int r = idx / NC, c = idx - r * NC;
+        if (v[u] != 0.0) {
+            src[idx] = 0.0;
+#ifndef NO_FLUSH
+            if (r0 + r < nao && c0 + c < nao) atomic_add_f64(out + (size_t)(r0 + r) * nao + c0 + c, v[u]);
+#endif
+        }
+    }
+}
+#define flush_tile(src, out, nao, r0, c0, NR, NC, tid) flush_tile_t<NR, NC>(src, out, nao, r0, c0, tid)
+// two-step form: every LDS element of every tile is read (and cleared) first, the global atomics of all tiles follow with no
+// LDS access between them (the compiler puts an `s_waitcnt vmcnt(0)` in front of an LDS store that follows a global atomic)
+template <int NR, int NC> struct FlushRegs { double v[(NR * NC + TBLOCK - 1) / TBLOCK]; };
+template <int NR, int NC>
+__device__ __forceinline__ void flush_read(FlushRegs<NR, NC>& f, double* __restrict__ src, const int tid)
+{
+#pragma unroll
+    for (int u = 0; u < (NR * NC + TBLOCK - 1) / TBLOCK; u++) {
+        const int idx = tid + u * TBLOCK;
+        f.v[u] = idx < NR * NC ? src[idx] : 0.0;
+        if (f.v[u] != 0.0) src[idx] = 0.0;
+    }
+}
+template <int NR, int NC>
+__device__ __forceinline__ void flush_atomics(const FlushRegs<NR, NC>& f, double* __restrict__ out, const int nao, const int r0,
+                                              const int c0, const int tid)
+{
+#pragma unroll
+    for (int u = 0; u < (NR * NC + TBLOCK - 1) / TBLOCK; u++) {
+        const int idx = tid + u * TBLOCK;
+        const int r = idx / NC, c = idx - r * NC;
+#ifndef NO_FLUSH
+        if (f.v[u] != 0.0 && r0 + r < nao && c0 + c < nao) atomic_add_f64(out + (size_t)(r0 + r) * nao + c0 + c, f.v[u]);
+#endif
+    }
+}
+#else
 __device__ __forceinline__ void flush_tile(double* __restrict__ src, double* __restrict__ out, const int nao,
                                            const int r0, const int c0, const int NR, const int NC, const int tid)
 {
@@ -227,6 +316,7 @@ __device__ __forceinline__ void flush_tile(double* __restrict__ src, double* __r
         }
     }
 }
+#endif
 
 __device__ __forceinline__ void lds_add(double* p, double v) { atomicAdd(p, v); }   // ds_add_f64
 
@@ -452,6 +542,115 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             asm volatile("" : "+v"(tid_s));
 #define tid tid_s
             if (tid == 0) s_nact[parity ^ 1] = 0;          // next iteration's counter (last read before this point)
+#if STAGE_ALL
+            // ---- every global load of EVERY ket slot is issued before the first use of any of them: one L2 round trip per
+            //      iteration instead of one per slot (the screening of a slot waits for its gathers, and a vmcnt wait covers
+            //      every older load as well)
+            constexpr int NPK = (TSK * TSL * 27 + TBLOCK - 1) / TBLOCK;
+            constexpr int NR = (NQ + TBLOCK - 1) / TBLOCK;           // screening rounds per slot
+            real rb_[NKS], rpk_[NKS][NPK];
+#if DO_J
+            TileRegs<WL, WK> rkl_[NKS];
+#endif
+#if DO_K
+            TileRegs<WI, WK> rik_[NKS];
+            TileRegs<WI, WL> ril_[NKS];
+            TileRegs<WJ, WK> rjk_[NKS];
+            TileRegs<WJ, WL> rjl_[NKS];
+#endif
+            float sq_[NKS][NR], sdv_[NKS][NR][6];
+            bool can_[NKS][NR];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                rb_[ks] = 0;
+                if (!kval[ks]) continue;
+                const int ksh0 = ksh0s[ks], lsh0 = lsh0s[ks], k0 = k0s[ks], l0 = l0s[ks];
+                if (tid < (TSK + TSL) * BASIS_STRIDE) {
+                    const int sl = tid / BASIS_STRIDE, w = tid - sl * BASIS_STRIDE;
+                    rb_[ks] = basis[(sl < TSK ? ksh0 + sl : lsh0 + sl - TSK) * BASIS_STRIDE + w];
+                }
+                const real* __restrict__ ppk = pair_tab + (size_t)tpair_pp[kl0 + kt + ks] * 27;
+#pragma unroll
+                for (int u = 0; u < NPK; u++) rpk_[ks][u] = tid + u * TBLOCK < TSK * TSL * 27 ? ppk[tid + u * TBLOCK] : real(0);
+#if DO_J
+                tile_load(rkl_[ks], D, nao, l0, k0, tid);
+#endif
+#if DO_K
+                tile_load(rik_[ks], D, nao, i0, k0, tid);
+                tile_load(ril_[ks], D, nao, i0, l0, tid);
+                tile_load(rjk_[ks], D, nao, j0, k0, tid);
+                tile_load(rjl_[ks], D, nao, j0, l0, tid);
+#endif
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const int cd = cand_lo + r * TBLOCK + tid;
+                    can_[ks][r] = false;
+                    sq_[ks][r] = 0;
+#pragma unroll
+                    for (int n = 0; n < 6; n++) sdv_[ks][r][n] = -36.8f;
+                    if (cd < cand_hi) {
+                        const int a = cd % TSI, b = (cd / TSI) % TSJ, d = (cd / (TSI * TSJ)) % TSL;
+                        const int c = QC(cd / (TSI * TSJ * TSL), a, b, d);
+                        const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
+                        if (ish >= jsh && ksh >= lsh && ish * nbas + jsh >= ksh * nbas + lsh) {
+                            can_[ks][r] = true;
+                            sq_[ks][r] = q_cond[ish * nbas + jsh] + q_cond[ksh * nbas + lsh];
+#if DO_K
+                            sdv_[ks][r][0] = log_dm[ish * nbas + ksh];
+                            sdv_[ks][r][1] = log_dm[jsh * nbas + ksh];
+                            sdv_[ks][r][2] = log_dm[ish * nbas + lsh];
+                            sdv_[ks][r][3] = log_dm[jsh * nbas + lsh];
+#endif
+#if DO_J
+                            sdv_[ks][r][4] = log_dm[ish * nbas + jsh];
+                            sdv_[ks][r][5] = log_dm[ksh * nbas + lsh];
+#endif
+                        }
+                    }
+                }
+            }
+            STAMP(3);
+            // ---- screening predicate, survivors of every wave appended to the queue through one LDS counter
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                if (!kval[ks]) continue;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    if (cand_lo + r * TBLOCK >= cand_hi) continue;
+                    const int cd = cand_lo + r * TBLOCK + tid;
+                    float sd = -36.8f;
+#pragma unroll
+                    for (int n = 0; n < 6; n++) sd = fmaxf(sd, sdv_[ks][r][n]);
+                    const float dq = sq_[ks][r] + sd;
+                    const bool keep = can_[ks][r] && dq > cut_lo && dq <= cut_hi;
+                    const unsigned long long m = __ballot(keep);
+                    if (m) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&s_nact[parity], (unsigned)__popcll(m));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (keep) s_act[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(cd | (ks << KS_SHIFT));
+                    }
+                }
+            }
+            // ---- write LDS
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                if (!kval[ks]) continue;
+                if (tid < (TSK + TSL) * BASIS_STRIDE) sBas[OFF_K + ks * KSTR + tid] = rb_[ks];
+#pragma unroll
+                for (int u = 0; u < NPK; u++)
+                    if (tid + u * TBLOCK < TSK * TSL * 27) sPK[ks * (TSK * TSL * 27) + tid + u * TBLOCK] = rpk_[ks][u];
+#if DO_J
+                tile_store(sDkl + ks * (WL * WK), rkl_[ks], tid);
+#endif
+#if DO_K
+                tile_store(sDik + ks * (WI * WK), rik_[ks], tid);
+                tile_store(sDil + ks * (WI * WL), ril_[ks], tid);
+                tile_store(sDjk + ks * (WJ * WK), rjk_[ks], tid);
+                tile_store(sDjl + ks * (WJ * WL), rjl_[ks], tid);
+#endif
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < NKS; ks++) {
                 if (!kval[ks]) continue;
@@ -532,6 +731,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 tile_store(sDjl + ks * (WJ * WL), rjl, tid);
 #endif
             }
+#endif  // STAGE_ALL
 #undef tid
             const int ksh0 = ksh0s[0], lsh0 = lsh0s[0], k0 = k0s[0], l0 = l0s[0];      // (row-lane mode: one ket pair)
             STAMP(4);
@@ -570,6 +770,12 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             double* const sJij_r = sJij;
             for (int q1 = tid; q1 < ((ABL & 16) ? 0 : nact); q1 += TBLOCK) {
                 const int qe = s_act[q1];
+#endif
+#if STAMPS
+                // (diagnostic) slot 13: active lanes of wave 0 summed over its batches; slot 10: time from the end of the previous
+                // batch to here (queue read, loop control)
+                if (tid == 0) st_acc[13] += __popcll(__ballot(true));
+                STAMP(10);
 #endif
                 const int ks = NKS > 1 ? qe >> KS_SHIFT : 0, qd = NKS > 1 ? qe & ((1 << KS_SHIFT) - 1) : qe;
                 const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
@@ -647,6 +853,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         }
                     }
                 }
+                STAMP(11);          // (diagnostic) integral evaluation of this batch
                 const int iA = a * NFI, jA = b * NFJ, kA = c * NFK, lA = d * NFL;
                 // ket-slot views of the ket-dependent tiles
                 const real* sDkl_q = sDkl + ks * (WL * WK); const real* sDik_q = sDik + ks * (WI * WK);
@@ -655,7 +862,111 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 double* sJkl_q = sJkl + ks * (WL * WK); double* sKik_q = sKik + ks * (WI * WK);
                 double* sKil_q = sKil + ks * (WI * WL); double* sKjk_q = sKjk + ks * (WJ * WK);
                 double* sKjl_q = sKjl + ks * (WJ * WL);
-#if CORD
+#if CTWO
+                {
+                    // ---- sweep 1: outputs of row i (J_ij, K_ik, K_il); live: D_kl, D_jl, D_jk
+                    {
+                        real dkl[NFK * NFL], djk[NFJ * NFK], djl[NFJ * NFL];
+#pragma unroll
+                        for (int k = 0; k < NFK; k++)
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) dkl[k * NFL + l] = DO_J ? DLD(sDkl_q[(lA + l) * WK + kA + k]) : real(0);
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) djk[j * NFK + k] = DO_K ? DLD(sDjk_q[(jA + j) * WK + kA + k]) : real(0);
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) djl[j * NFL + l] = DO_K ? DLD(sDjl_q[(jA + j) * WL + lA + l]) : real(0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NFI; i++) {
+                            real sij[NFJ], kik[NFK], kil[NFL];
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++) sij[j] = 0;
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) kik[k] = 0;
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) kil[l] = 0;
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                                for (int k = 0; k < NFK; k++)
+#pragma unroll
+                                    for (int l = 0; l < NFL; l++) {
+                                        const real v = I[((i * NFJ + j) * NFK + k) * NFL + l];
+#if DO_J
+                                        sij[j] += v * dkl[k * NFL + l];
+#endif
+#if DO_K
+                                        kik[k] += v * djl[j * NFL + l];
+                                        kil[l] += v * djk[j * NFK + k];
+#endif
+                                    }
+#if DO_J
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++) LDS_ADD(&sJij_r[(jA + j) * WI + iA + i], (double)sij[j]);
+#endif
+#if DO_K
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) LDS_ADD(&sKik_q[(iA + i) * WK + kA + k], (double)kik[k]);
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) LDS_ADD(&sKil_q[(iA + i) * WL + lA + l], (double)kil[l]);
+#endif
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- sweep 2: outputs accumulated over i (J_kl, K_jk, K_jl); live: the accumulators and one row of D_ij, D_ik, D_il
+                    {
+                        real jkl[NFK * NFL], kjk[NFJ * NFK], kjl[NFJ * NFL];
+#pragma unroll
+                        for (int n = 0; n < NFK * NFL; n++) jkl[n] = 0;
+#pragma unroll
+                        for (int n = 0; n < NFJ * NFK; n++) kjk[n] = 0;
+#pragma unroll
+                        for (int n = 0; n < NFJ * NFL; n++) kjl[n] = 0;
+#pragma unroll
+                        for (int i = 0; i < NFI; i++) {
+                            real dij[NFJ], dik[NFK], dil[NFL];
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++) dij[j] = DO_J ? DLD(sDij[(jA + j) * WI + iA + i]) : real(0);
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) dik[k] = DO_K ? DLD(sDik_q[(iA + i) * WK + kA + k]) : real(0);
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) dil[l] = DO_K ? DLD(sDil_q[(iA + i) * WL + lA + l]) : real(0);
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                                for (int k = 0; k < NFK; k++)
+#pragma unroll
+                                    for (int l = 0; l < NFL; l++) {
+                                        const real v = I[((i * NFJ + j) * NFK + k) * NFL + l];
+#if DO_J
+                                        jkl[k * NFL + l] += v * dij[j];
+#endif
+#if DO_K
+                                        kjk[j * NFK + k] += v * dil[l];
+                                        kjl[j * NFL + l] += v * dik[k];
+#endif
+                                    }
+                        }
+#if DO_J
+#pragma unroll
+                        for (int k = 0; k < NFK; k++)
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) LDS_ADD(&sJkl_q[(lA + l) * WK + kA + k], (double)jkl[k * NFL + l]);
+#endif
+#if DO_K
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                            for (int k = 0; k < NFK; k++) LDS_ADD(&sKjk_q[(jA + j) * WK + kA + k], (double)kjk[j * NFK + k]);
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) LDS_ADD(&sKjl_q[(jA + j) * WL + lA + l], (double)kjl[j * NFL + l]);
+                        }
+#endif
+                    }
+                }
+#elif CORD
                 {
                     // ---- contraction, row by row in i: the density reads of row i + 1 are issued BEFORE the LDS atomics of
                     //      row i (the DS queue is in order: a read queued behind a same-address atomic waits for its lanes)
@@ -810,6 +1121,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
 #endif
             #endif  // CORD
+                STAMP(12);          // (diagnostic) contraction + LDS atomics of this batch
 }
 #if ABL & 2
             if (abl_sink == 1.2345e300) sJij[0] = abl_sink;
@@ -1239,6 +1551,47 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             double* __restrict__ vj = kf->vj;
             double* __restrict__ vk = kf->vk;
 #endif
+#if FLUSH_UNROLL == 2
+            {
+#if DO_J
+                FlushRegs<WL, WK> fkl[NKS];
+#endif
+#if DO_K
+                FlushRegs<WI, WK> fik[NKS];
+                FlushRegs<WI, WL> fil[NKS];
+                FlushRegs<WJ, WK> fjk[NKS];
+                FlushRegs<WJ, WL> fjl[NKS];
+#endif
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    if (!kval[ks]) continue;
+#if DO_J
+                    flush_read(fkl[ks], sJkl + ks * (WL * WK), tid);
+#endif
+#if DO_K
+                    flush_read(fik[ks], sKik + ks * (WI * WK), tid);
+                    flush_read(fil[ks], sKil + ks * (WI * WL), tid);
+                    flush_read(fjk[ks], sKjk + ks * (WJ * WK), tid);
+                    flush_read(fjl[ks], sKjl + ks * (WJ * WL), tid);
+#endif
+                }
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    if (!kval[ks]) continue;
+                    const int k0 = k0s[ks], l0 = l0s[ks];
+#if DO_J
+                    flush_atomics(fkl[ks], vj + idm * nao2, nao, l0, k0, tid);
+#endif
+#if DO_K
+                    double* __restrict__ K = vk + idm * nao2;
+                    flush_atomics(fik[ks], K, nao, i0, k0, tid);
+                    flush_atomics(fil[ks], K, nao, i0, l0, tid);
+                    flush_atomics(fjk[ks], K, nao, j0, k0, tid);
+                    flush_atomics(fjl[ks], K, nao, j0, l0, tid);
+#endif
+                }
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < NKS; ks++) {
                 if (!kval[ks]) continue;
@@ -1254,6 +1607,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 flush_tile(sKjl + ks * (WJ * WL), K, nao, j0, l0, WJ, WL, tid);
 #endif
             }
+#endif
             }
 #undef tid
             STAMP(8);

@@ -81,7 +81,7 @@ def test_fp32_window_and_pair_cutoff():
     from joltqc_amd.pyscf import rks
     from joltqc_amd.pyscf.basis import BasisLayout
     from oracle import dft
-    mol = mole.Mole(atom=benzene_like(), basis="def2-svp")
+    mol = mole.Mole(atom=benzene_like(), basis="def2-svp")          # two rings 14 Bohr apart: many weak AO pairs per block
     lay = BasisLayout.from_mol(mol, alignment=1)
     grids = Grids(mol, 8192)
     _, rho64, vxc64 = rks.generate_rks_kernel(lay, cutoff_fp64=1e-13, cutoff_fp32=1e-13)
@@ -102,7 +102,8 @@ def test_fp32_window_and_pair_cutoff():
 
 def benzene_like():
     from conftest import benzene_atoms
-    return benzene_atoms()
+    ring = benzene_atoms()
+    return ring + [(sym, (x + 7.4, y + 0.5, z + 1.0)) for sym, (x, y, z) in ring]
 
 
 def test_vv10_kernel_and_driver():
@@ -168,9 +169,14 @@ def test_rks_scf_through_apply_matches_cpu_oracle_scf():
     coords = at[rng.integers(0, 3, 6000)] + rng.normal(0, 1.0, (6000, 3))
     coords = coords[np.lexsort(coords.T)]
     weights = np.full(6000, 0.004)
-    mf = jp.apply(RKS(mol, T + V, S, G(coords, weights)))
+    # all-FP64 grid path for the 1e-8 comparison; the default DFT config (cutoff_fp64 = 1e-6, reference
+    # __init__.py:100-118) sends the weak AO pairs through the FP32 MFMA and is checked to the reference's own 1e-6 below
+    cfg = jp.get_default_config()
+    cfg["dft"] = {"cutoff_fp32": 1e-13, "cutoff_fp64": 1e-13}
+    mf = jp.apply(RKS(mol, T + V, S, G(coords, weights)), cfg)
     assert mf._joltqc_applied and mf.get_veff.__func__.__name__ == "get_veff"
     e_gpu = mf.kernel()
+    e_default = jp.apply(RKS(mol, T + V, S, G(coords, weights))).kernel()
 
     ref = RKS(mol, T + V, S, G(coords, weights))
     q = dense.canonical_quartets(lay)
@@ -187,3 +193,4 @@ def test_rks_scf_through_apply_matches_cpu_oracle_scf():
     e_cpu = ref.kernel()
     assert mf.converged and ref.converged
     assert abs(e_gpu - e_cpu) < 1e-8, e_gpu - e_cpu
+    assert abs(e_default - e_cpu) < 1e-6, e_default - e_cpu
