@@ -32,6 +32,7 @@ PAIR_CUTOFF = 1e-13      # reference jk_pair.py:44
 PAIR_WIDE_VJ = 256       # bra pairs per workgroup (reference :45)
 PAIR_WIDE_VK = 64        # reference :46 (unused here, see module docstring)
 TARGET_WGS = 2048        # a launch is split over the ket list until it has about this many workgroups
+PAIR_MAX_L = 3           # highest angular momentum with ahead-of-time pair kernels (__graft_entry__._compile_pair)
 
 
 def generate_get_j(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, pair_wide_vk=PAIR_WIDE_VK):
@@ -99,18 +100,26 @@ class _ClassPairs:
                             "nprim": [(int(gkey[s[0], 1]), int(gkey[s[1], 1])) for s in segs]}
 
 
-def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, pair_wide_vk=PAIR_WIDE_VK):
+def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, pair_wide_vk=PAIR_WIDE_VK, tile_jk=None,
+                       max_l=PAIR_MAX_L):
     """Pair-based ``get_jk`` for ``basis_layout`` (a tile-aligned layout, as for ``jk.generate_jk_kernel``).  FP64 only:
-    ``cutoff_fp32`` is the screening threshold, ``cutoff_fp64`` is accepted for interface parity."""
+    ``cutoff_fp32`` is the screening threshold, ``cutoff_fp64`` is accepted for interface parity.  ``tile_jk``: an existing
+    tiled ``get_jk`` of the same layout and cutoffs to share (K and the J classes without a pair kernel go through it);
+    ``max_l``: classes with a higher angular momentum stay on the tiled kernels (their pair kernels are not in the
+    ahead-of-time set of ``__graft_entry__.build`` and take minutes to generate)."""
+    import os
     import torch
     layout = basis_layout
     nao, nbas = layout.nao, layout.nbasis
     log_cutoff = float(np.float32(math.log(min(cutoff_fp32, cutoff_fp64))))
-    tile_jk = _jk.generate_jk_kernel(layout, cutoff_fp64=cutoff_fp64, cutoff_fp32=cutoff_fp32)
-    state = {"pairs": {}, "stats": {}}
+    if tile_jk is None:
+        tile_jk = _jk.generate_jk_kernel(layout, cutoff_fp64=cutoff_fp64, cutoff_fp32=cutoff_fp32)
+    state = {"pairs": {}, "stats": {}, "checked": set()}
 
     def supported(ab, cd, lr):
         """Both directions of the canonical class (ab|cd) have a spill-free pair kernel."""
+        if max(ab + cd) > max_l:
+            return False
         return pair_kernel(*ab, *cd, lr=lr) is not None and pair_kernel(*cd, *ab, lr=lr) is not None
 
     def get_jk(mol_ref=None, dm=None, hermi=0, vhfopt=None, with_j=True, with_k=True, omega=None, verbose=None):
@@ -194,6 +203,16 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, pair_
                 # (the tiled path sees the full D; for hermi = 0 it stacks [D, D^T] itself)
                 vj = vj + tile_jk(mol_ref, dm_t, hermi, vhfopt, True, False, omega, verbose, _classes=lambda q: tuple(q) in keep)[0]
             state["stats"].update(pair_launches=n_launch, pair_counter=counter, pair_classes=len(on_pairs), tile_classes=len(on_tiles))
+            # first J of this closure (per range-separation mode): cross-check the pair kernels against the tiled J kernels
+            # on this call's own density, as jk.first_use_check does for tile builds outside the verified manifest
+            if lr not in state["checked"] and os.environ.get("JQC_TRUST_KERNELS") != "1":
+                ref = tile_jk(mol_ref, dm_t, hermi, vhfopt, True, False, omega, verbose)[0]
+                scale = float(ref.abs().max().item())
+                err = float((vj - ref).abs().max().item())
+                if not err <= 1e-9 * max(scale, 1e-300):
+                    raise RuntimeError(f"pair-based J disagrees with the tiled J kernels on its first use (max |diff| {err:.3e}, "
+                                       f"largest element {scale:.3e}): the pair kernels are rejected")
+            state["checked"].add(lr)
         if isinstance(dm_in, np.ndarray) and getattr(get_jk, "return_numpy", False):
             vj = vj.cpu().numpy() if with_j else 0
             vk = vk.cpu().numpy() if with_k else 0

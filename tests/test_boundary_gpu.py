@@ -50,6 +50,35 @@ def test_numpy_in_numpy_out_on_a_cpu_object():
     assert isinstance(vhf2, np.ndarray) and np.abs(vhf2 - 1.01 * vhf).max() < 1e-9 * np.abs(vhf).max()
 
 
+def test_get_j_goes_through_the_pair_backend_by_default():
+    """apply() routes J-only calls to the pair-based Coulomb kernels (config jk.pair_j, single GPU, all-FP64): same numbers as
+    the J of get_jk, NumPy at the boundary, the first call cross-checked against the tiled J kernels; pair_j = False keeps the
+    tiled kernels."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from standin_scf import RHF
+    mol = mole.Mole(atom=H2O, basis="def2-tzvpp")
+    mf = jp.apply(RHF(mol, int1e=_int1e))
+    np.random.seed(3)
+    dm = np.random.rand(mol.nao, mol.nao) - 0.5
+    dm = dm + dm.T
+    vj = mf.get_j(mol, dm, hermi=1)
+    st = mf._jqc_pair_jk.stats
+    assert isinstance(vj, np.ndarray) and st["pair_launches"] > 0 and st["pair_classes"] > 0
+    ref = mf.get_jk(mol, dm, hermi=1)[0]
+    assert np.abs(vj - ref).max() < 1e-11 * np.abs(ref).max()
+    vj3 = mf.get_j(mol, np.stack([dm, 2 * dm, dm @ dm]), hermi=0)          # several densities, non-symmetric one included
+    ref3 = mf.get_jk(mol, np.stack([dm, 2 * dm, dm @ dm]), hermi=0)[0]
+    assert vj3.shape == (3,) + dm.shape and np.abs(vj3 - ref3).max() < 1e-11 * np.abs(ref3).max()
+    vlr = mf.get_j(mol, dm, hermi=1, omega=0.3)
+    assert np.abs(vlr - mf.get_jk(mol, dm, hermi=1, omega=0.3)[0]).max() < 1e-11 * np.abs(ref).max()
+    cfg = jp.get_default_config()
+    cfg["jk"]["pair_j"] = False
+    mf2 = jp.apply(RHF(mol, int1e=_int1e), cfg)
+    assert not hasattr(mf2, "_jqc_pair_jk")
+    assert np.abs(mf2.get_j(mol, dm, hermi=1) - ref).max() < 1e-11 * np.abs(ref).max()
+
+
 def test_reset_and_scanner_follow_a_geometry_change():
     import joltqc_amd.pyscf as jp
     from joltqc_amd.gto import mole
