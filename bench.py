@@ -137,7 +137,7 @@ def committed_traffic(kernel):
     return None
 
 
-def grid_leg(mol, nsteps=3):
+def grid_leg(mol, nsteps=5):
     """rho / vxc (GGA) throughput on a Becke grid; algorithmic flops = 256 (2 m^2 + 8 m) per block of m significant AOs."""
     import torch
     from joltqc_amd.pyscf import rks
@@ -165,16 +165,19 @@ def grid_leg(mol, nsteps=3):
     out = {"xc": "GGA", "ngrids": n, "nao": mol.nao, "grid": f"Becke, {per} points per atom (30 radial x 128 angular), box-sorted"}
     for fn, arg, label in ((rho_k, dm, "rho"), (vxc_k, wv, "vxc")):
         fn(mol, g, "GGA", arg); torch.cuda.synchronize()
-        t = time.perf_counter()
+        each = []
         for _ in range(nsteps):
+            t = time.perf_counter()
             fn(mol, g, "GGA", arg)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t) / nsteps
+            torch.cuda.synchronize()
+            each.append(time.perf_counter() - t)
+        dt = sum(each) / nsteps
         m = rho_k.stats["nrow_h"].astype(float)                      # significant Cartesian AOs per 256-point block
         pairs = float((m * m).sum()) * 256                            # grid points x AO pairs actually contracted
         fl = 2.0 * pairs + 8.0 * 256 * float(m.sum())                # 256 (2 m^2 + 8 m) per block
         out[label] = {"ms": dt * 1e3, "points_x_ao_pairs_per_s": pairs / dt, "tflops": fl / dt / 1e12,
-                      "frac_fp64_mfma_peak": fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS, "mean_ao_per_block": float(m.mean())}
+                      "frac_fp64_mfma_peak": fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS, "mean_ao_per_block": float(m.mean()),
+                      "ms_each_step": [round(x * 1e3, 3) for x in each]}
     # the same two calls with the default DFT cutoffs of apply() (cutoff_fp64 = 1e-6: weak AO pairs through the FP32 MFMA)
     _, rho_m, vxc_m = rks.generate_rks_kernel(lay, cutoff_fp64=1e-6, cutoff_fp32=1e-13)
     for fn, arg, label in ((rho_m, dm, "rho"), (vxc_m, wv, "vxc")):

@@ -29,6 +29,7 @@ extern "C" {
 #define JQC_ALGO_TILE1Q 2 /* one quartet per lane inside the same LDS tile framework (small classes) */
 #define JQC_ALGO_TILE512 3 /* JQC_ALGO_TILE with 512-thread workgroups: two waves per SIMD on one set of LDS tiles */
 #define JQC_ALGO_PAIRVJ 8  /* pair-based J kernel (jqc_gen_pair_vj_kernel) */
+#define JQC_ALGO_JKGRAD 9  /* nuclear-gradient kernel of the two-electron energy (jqc_gen_jk_grad_kernel) */
 /* Tuning variant of a tiled kernel, OR-ed into the `algo` argument of jqc_gen_jk_kernel (gfx950 scheme table): */
 #define JQC_VARIANT_MINW(n) ((n) << 4) /* waves per SIMD the register allocation leaves room for (0 = kernel default) */
 #define JQC_VARIANT_RYS_L2 (1 << 8)    /* read the Rys table through L2 instead of staging it in LDS */
@@ -49,6 +50,8 @@ const char* jqc_last_error(void);
 const char* jqc_version(void);
 /* tag (hash of the kernel sources) embedded in every cached code-object name; valid after jqc_set_kernel_dirs */
 const char* jqc_source_tag(void);
+/* the same for the gradient kernels (jk_grad.hip on top of the sources above) */
+const char* jqc_grad_source_tag(void);
 
 /* Runtime set-up.  src_dir holds the kernel sources (joltqc_amd/csrc/kernels), cache_dir receives
  * the gfx950 code objects (one .hsaco per class/variant; replaces CuPy's cubin cache, examples/04). */
@@ -155,6 +158,21 @@ int jqc_pair_vj_launch(int handle, int nao, const double* basis_d, const double*
                        const uint32_t* ket_pairs_d, const float* ket_q_d, const float* ket_ld_d, const double* ket_tab_d,
                        const int32_t* ket_seg_d, int nseg, float log_cut, float log_max_dm, int npi, int npj, int nsplit,
                        uint64_t* counter_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------ nuclear gradient of E2
+ * SURVEY.md 8(f) row 3.  The reference has no gradient kernels (its scanners take GPU4PySCF's CUDA gradients,
+ * jqc/pyscf/__init__.py:63-97); the host-side counterpart these two calls replace is GPU4PySCF's per-atom J/K energy
+ * derivative (gpu4pyscf.grad.rhf `_jk_energy_per_atom(mol, dm, vhfopt, j_factor, k_factor)`).
+ * jqc_gen_jk_grad_kernel: code object of csrc/kernels/jk_grad.hip for class (li lj|lk ll), canonical order; FP64 only.
+ * jqc_jk_grad_launch: for every quartet of the queue (same ushort4 entries and device-side count as jqc_jk_launch)
+ *   grad_d[rep][atom][3] += d/dR_atom of  sum_abcd (ab|cd) [4 j_factor D_ab D_cd - k_factor n_dm sum_s (D^s_ac D^s_bd + D^s_ad D^s_bc)]
+ *   with D = sum_s D^s, dm_d = n_dm (1 or 2) symmetric matrices [nao, nao] in the internal Cartesian order, shell_atom_d[nbas]
+ *   = atom of every internal shell, rep = workgroup index mod nrep (the caller sums the nrep replicas).  With j_factor =
+ *   k_factor = 1 and the total closed-shell density this is the gradient of 1/2 tr(D J) - 1/4 tr(D K) at fixed D. */
+int jqc_gen_jk_grad_kernel(int li, int lj, int lk, int ll, int rys_lr, int compile_only);
+int jqc_jk_grad_launch(int handle, int nao, const double* basis_d, const double* dm_d, int n_dm, double* grad_d,
+                       const int32_t* shell_atom_d, int natm, int nrep, double j_factor, double k_factor, double omega,
+                       const void* quartets_d, const uint32_t* ntasks_d, int64_t ntasks_max, int qstride, void* stream);
 
 /* Schwarz bounds on device (replaces the libcvhf call in compute_q_matrix, jqc/pyscf/basis.py:840-867):
  * for each listed pair p = (ish<<16|jsh) with l(ish)=li, l(jsh)=lj:  out[p] = sqrt(max_ab |(ab|ab)|). */

@@ -71,6 +71,9 @@ def lib():
         L.jqc_int1e.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
         L.jqc_gen_pair_vj_kernel.argtypes = [i32] * 6
         L.jqc_pair_ntrip.argtypes = [i32, i32]
+        L.jqc_gen_jk_grad_kernel.argtypes = [i32] * 6
+        L.jqc_jk_grad_launch.argtypes = [i32, i32, vp, vp, i32, vp, vp, i32, i32, f64, f64, f64, vp, vp, i64, i32, vp]
+        L.jqc_grad_source_tag.restype = c.c_char_p
         L.jqc_pair_ket_density.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp, vp]
         L.jqc_pair_vj_launch.argtypes = [i32, i32, vp, vp, vp, f64, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, i32,
                                          i32, vp, vp]
@@ -92,9 +95,10 @@ def lib():
 def purge_stale_cache():
     """Remove cached code objects that were built from other versions of the kernel sources."""
     tag = lib().jqc_source_tag().decode()
+    gtag = lib().jqc_grad_source_tag().decode()
     n = 0
     for f in os.listdir(KERNEL_CACHE):
-        if f.endswith(".hsaco") and not f.endswith("_" + tag + ".hsaco"):
+        if f.endswith(".hsaco") and not f.endswith("_" + tag + ".hsaco") and not f.endswith("_" + gtag + ".hsaco"):
             os.remove(os.path.join(KERNEL_CACHE, f))
             n += 1
     return n

@@ -32,6 +32,8 @@ std::mutex g_mu;
 std::string g_src_dir, g_cache_dir;
 int g_tsw[5] = {8, 4, 4, 2, 1};     // shells per tile edge by angular momentum (jqc_set_tile_widths)
 std::string g_src_tag = "nosrc";   // FNV-1a of every kernel source: stale code objects are never reused
+std::string g_grad_tag = "nosrc";  // same for the gradient kernels (jk_grad.hip + the headers it includes), kept apart so that
+                                   // work on them does not invalidate the verified J/K code objects
 
 int fail(int code, const char* fmt, ...)
 {
@@ -518,6 +520,7 @@ extern "C" {
 const char* jqc_last_error(void) { return g_err.c_str(); }
 const char* jqc_version(void) { return "joltqc_amd 0.1 (gfx950)"; }
 const char* jqc_source_tag(void) { return g_src_tag.c_str(); }
+const char* jqc_grad_source_tag(void) { return g_grad_tag.c_str(); }
 
 int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
 {
@@ -547,6 +550,12 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
     char tag[32];
     snprintf(tag, sizeof tag, "%010llx", h & 0xffffffffffull);
     g_src_tag = tag;
+    {
+        const std::string txt = read_file(g_src_dir + "/jk_grad.hip");
+        for (unsigned char ch : txt) { h ^= ch; h *= 1099511628211ull; }
+        snprintf(tag, sizeof tag, "%010llx", h & 0xffffffffffull);
+        g_grad_tag = tag;
+    }
     return 0;
 }
 
@@ -772,6 +781,69 @@ int jqc_gen_pair_vj_kernel(int li, int lj, int lk, int ll, int rys_lr, int compi
     return h;
 }
 
+int jqc_gen_jk_grad_kernel(int li, int lj, int lk, int ll, int rys_lr, int compile_only)
+{
+    std::lock_guard<std::mutex> lk_(g_mu);
+    if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
+        return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
+    char key[96];
+    snprintf(key, sizeof key, "jkgrad_%d%d%d%d_lr%d", li, lj, lk, ll, rys_lr);
+    auto it = g_by_key.find(key);
+    if (it != g_by_key.end() && (compile_only || g_kernels[it->second].fn)) return it->second;
+    char entry[64];
+    snprintf(entry, sizeof entry, "jk_grad_%d%d%d%d", li, lj, lk, ll);
+    const std::string out = g_cache_dir + "/" + key + "_" + g_grad_tag + ".hsaco";
+    if (!file_exists(out)) {
+        int rc = compile_to("jk_grad.hip", {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
+                                            "-DLK=" + std::to_string(lk), "-DLL=" + std::to_string(ll),
+                                            "-DRYS_LR=" + std::to_string(rys_lr), "-DFP32=0", "-DDO_J=1", "-DDO_K=1",
+                                            std::string("-DKNAME=") + entry}, out);
+        if (rc) return rc;
+    }
+    Kernel k;
+    k.key = key;
+    k.li = li; k.lj = lj; k.lk = lk; k.ll = ll; k.algo = JQC_ALGO_JKGRAD;
+    k.nroots = (li + lj + lk + ll + 1) / 2 + 1;          // one derivative: one more order
+    if (!compile_only) {
+        int rc = load_kernel(out, entry, k);
+        if (rc) return rc;
+    }
+    int h;
+    if (it != g_by_key.end()) {
+        h = it->second;
+        g_kernels[h] = k;
+    } else {
+        h = (int)g_kernels.size();
+        g_kernels.push_back(k);
+        g_by_key[key] = h;
+    }
+    return h;
+}
+
+int jqc_jk_grad_launch(int handle, int nao, const double* basis_d, const double* dm_d, int n_dm, double* grad_d,
+                       const int32_t* shell_atom_d, int natm, int nrep, double j_factor, double k_factor, double omega,
+                       const void* quartets_d, const uint32_t* ntasks_d, int64_t ntasks_max, int qstride, void* stream)
+{
+    KernelView k;
+    if (!kernel_view(handle, k)) return fail(-1, "invalid kernel handle %d", handle);
+    if (k.algo != JQC_ALGO_JKGRAD) return fail(-1, "handle %d is not a gradient kernel", handle);
+    if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
+    if (n_dm < 1 || n_dm > 2) return fail(-1, "n_dm = %d: one (closed shell) or two (alpha, beta) densities", n_dm);
+    if (k.nroots > (int)g_rys_host[0]) return fail(-1, "class needs %d Rys roots, tables hold %d", k.nroots, (int)g_rys_host[0]);
+    if (ntasks_max <= 0) return 0;
+    if (nrep < 1) nrep = 1;
+    const double* cheb = rys_cheb64(k.nroots);
+    const double* large = rys_large64(k.nroots);
+    void* args[] = {&nao, &basis_d, &dm_d, &n_dm, &grad_d, &shell_atom_d, &natm, &nrep, &j_factor, &k_factor, &omega,
+                    &quartets_d, &ntasks_d, &qstride, &cheb, &large};
+    const int block = 256;
+    int64_t blocks = (ntasks_max + block - 1) / block;
+    const int64_t cap = 256 * 64;  // grid-stride beyond this
+    if (blocks > cap) blocks = cap;
+    HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)blocks, 1, 1, block, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+    return 0;
+}
+
 int jqc_pair_ket_density(const double* basis_d, const double* dm_d, int nao, const uint32_t* ket_pairs_d, int n_ket, int lk,
                          int ll, double* E_d, float* ld_d, void* stream)
 {
@@ -940,7 +1012,7 @@ int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int
 {
     if (nblk <= 0) return 0;
     if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
-    hipLaunchKernelGGL(vxc_mfma_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+    hipLaunchKernelGGL(vxc_mfma_kernel, dim3(nblk), dim3(VXC_THREADS), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
                        (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, wv_d, ndim, nao, vmat_d, row_la_d, thr64, thr32);
     HIP_OK(hipGetLastError());
     return 0;

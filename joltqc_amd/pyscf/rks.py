@@ -27,7 +27,8 @@ __all__ = ["generate_rks_kernel", "generate_get_rho", "generate_nr_rks", "genera
 ao_cutoff = 1e-13                    # reference rks.py:55
 DIM_BY_XC = {"LDA": 1, "GGA": 4, "MGGA": 5}
 NG = 256
-WORKSPACE_BYTES = 6 << 30            # AO workspace per batch (HBM is 288 GB; blocks are batched to this size)
+WORKSPACE_BYTES = 6 << 30            # AO workspace per batch: floor; raised to WORKSPACE_FRACTION of the device memory
+WORKSPACE_FRACTION = 0.10            # (288 GB of HBM: 28 GB, i.e. a 112-atom / def2-TZVPP GGA grid of 3.7e5 points in ONE batch)
 
 
 def _t(x, dev):
@@ -89,10 +90,10 @@ class _GridCache:
         return self.sparsity[bucket]
 
 
-def _batches(nrow_h, ncomp):
+def _batches(nrow_h, ncomp, workspace_bytes=WORKSPACE_BYTES):
     """Split the blocks into batches whose padded AO rows fit the workspace; yields (blk0, nblk, row_base, rows)."""
     pad = (nrow_h + 15) // 16 * 16
-    max_rows = max(int(WORKSPACE_BYTES // (ncomp * NG * 8)), int(pad.max()) if pad.size else 16)
+    max_rows = max(int(workspace_bytes // (ncomp * NG * 8)), int(pad.max()) if pad.size else 16)
     b0, n = 0, len(pad)
     while b0 < n:
         acc, b1 = 0, b0
@@ -139,12 +140,21 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
             from .parallel import split_blocks
             b_lo, b_hi = split_blocks(nrow_h.astype(np.float64) ** 2 + 64.0 * nrow_h + 1.0, rank, nranks)
         state["stats"]["block_range"] = (b_lo, b_hi)
-        for blk0, nblk, base, rows in _batches(nrow_h[b_lo:b_hi], ncomp_ao):
-            blk0 += b_lo
+        # the batch plan (and its row-base table on the device) only depends on the shell lists: kept with them, so that a
+        # call issues no blocking host-to-device copy
+        pkey = (id(nrow_h), ncomp_ao, b_lo, b_hi)
+        plans = state.setdefault("plans", {})
+        if pkey not in plans or plans[pkey][0] is not nrow_h:          # (the array is kept: an id() can be reused)
+            cap = max(WORKSPACE_BYTES, int(WORKSPACE_FRACTION * torch.cuda.get_device_properties(dev).total_memory))
+            plan = []
+            for blk0, nblk, base, rows in _batches(nrow_h[b_lo:b_hi], ncomp_ao, cap):
+                plan.append((blk0 + b_lo, nblk, torch.from_numpy(base).to(dev), rows,
+                             torch.empty(rows, dtype=torch.int32, device=dev), torch.empty(rows, dtype=torch.float32, device=dev)))
+            if len(plans) > 8:
+                plans.clear()
+            plans[pkey] = (nrow_h, plan)
+        for blk0, nblk, base_d, rows, ao_idx, row_la in plans[pkey][1]:
             ws = _workspace(dev, rows, ncomp_ao)
-            base_d = torch.from_numpy(base).to(dev)
-            ao_idx = torch.empty(rows, dtype=torch.int32, device=dev)
-            row_la = torch.empty(rows, dtype=torch.float32, device=dev)
             comp_stride = rows * NG
             _lib.check(L.jqc_dft_eval_ao(soa.data_ptr(), gcache.ngrids_pad, basis.data_ptr(), layout.nbasis, blk0, nblk,
                                          shell_list.data_ptr(), row_of.data_ptr(), nshl.data_ptr(), nrow.data_ptr(),
