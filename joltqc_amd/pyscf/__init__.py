@@ -33,6 +33,10 @@ def get_default_config() -> Dict[str, Any]:
         # True: mf.get_hcore / mf.get_ovlp from the device kernels (joltqc_amd/pyscf/int1e.py) instead of the object's own
         # (PySCF: libcint on the CPU); objects with ECPs keep their own
         "int1e": False,
+        # True: RHF objects with ``nuc_grad_method`` (PySCF) get gradient objects whose ``grad_elec`` takes the two-electron term
+        # from the device kernels (joltqc_amd/pyscf/grad.py).  ``obj._jqc_jk_energy_per_atom`` is installed
+        # in any case.  Not in the reference, which leaves gradients to GPU4PySCF
+        "grad": False,
     }
 
 
@@ -138,6 +142,21 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
                 obj.get_k = lambda *a, **k: get_jk(*a, with_j=False, with_k=True, **k)[1]
         if _is(obj, "RHF") and not _is(obj, "RKS"):
             obj.get_veff = MethodType(_jk.generate_get_veff(), obj)
+        # gradient of the two-electron energy at fixed density (the closure does no device work until it is called)
+        from . import grad as _grad
+        jk_grad = _grad.generate_jk_energy_per_atom(basis_layout_jk, cutoff=min(jk_cutoff_fp32, jk_cutoff_fp64), shard=shard)
+        obj._jqc_jk_energy_per_atom = jk_grad
+        if config.get("grad") and _is(obj, "RHF") and not _is(obj, "RKS") and hasattr(obj, "nuc_grad_method") \
+                and not hasattr(obj, "_jqc_original_nuc_grad_method"):
+            original_ngm = obj.nuc_grad_method
+            obj._jqc_original_nuc_grad_method = original_ngm
+
+            def nuc_grad_method(*a, **k):
+                g = original_ngm(*a, **k)
+                g.grad_elec = lambda mo_energy=None, mo_coeff=None, mo_occ=None, atmlst=None: \
+                    _grad.rhf_grad_elec(obj, obj._jqc_jk_energy_per_atom)
+                return g
+            obj.nuc_grad_method = nuc_grad_method
 
     if config.get("int1e") and not getattr(obj.mol, "has_ecp", lambda: False)():
         from . import int1e as _int1e

@@ -1,0 +1,197 @@
+"""Nuclear gradient of the two-electron energy on the GPU (csrc/kernels/jk_grad.hip through the C ABI).
+
+The reference has no gradient kernels (it defers to GPU4PySCF, /root/reference/jqc/pyscf/tests/test_geom_opt.py:250-354), so
+the checks are: (1) the analytic oracle of oracle/grad.py (McMurchie-Davidson, pinned by finite differences of the pinned J/K
+oracle in tests/test_grad_oracle.py) on small systems, closed shell / two spin densities / long range / scaled J and K,
+spherical and Cartesian; (2) size-independent: the directional derivative of the GPU's own two-electron energy (the parity-green
+get_jk) along random displacements, for every angular class up to g (benzene with the artificial s..g basis), for
+benzene / def2-TZVPP and for the 112-atom stand-in with def2-SVP; translational invariance everywhere.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import H2O, benzene_atoms
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BASIS = {"O": [[0, [11.0, 0.3], [2.1, 0.5], [0.6, 0.4]], [1, [1.9, 0.6], [0.45, 0.5]], [2, [0.9, 1.0]]],
+         "H": [[0, [3.4, 0.2], [0.6, 0.8]], [1, [0.8, 1.0]]]}
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+@pytest.mark.parametrize("cart", [False, True])
+def test_gradient_kernels_against_the_analytic_oracle(cart):
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import grad
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import grad as G
+    mol = mole.Mole(atom="O 0 0.05 -0.1; H 0.3 1.1 1.45; H -1.2 0.4 -0.9", basis=BASIS, unit="B", cart=cart)
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    fn = grad.generate_jk_energy_per_atom(lay, cutoff=1e-16)
+    rng = np.random.default_rng(5)
+    n = mol.nao
+    d = rng.random((n, n)) - 0.3
+    a, b = rng.random((n, n)) - 0.4, rng.random((n, n)) - 0.6
+    cases = [(d + d.T, 1.0, 1.0, None), (d + d.T, 1.0, 0.0, None), (d + d.T, 0.0, 1.0, 0.3),
+             (np.stack([a + a.T, b + b.T]), 0.7, 0.35, None), (np.stack([a + a.T, b + b.T]), 0.0, 0.2, 0.4)]
+    for dm, jf, kf, om in cases:
+        ref = G.jk_energy_per_atom(lay, dm, jf, kf, om)
+        out = fn(mol, dm, j_factor=jf, k_factor=kf, omega=om)
+        assert isinstance(out, np.ndarray) and out.shape == (3, 3)
+        scale = np.abs(ref).max()
+        assert np.abs(out - ref).max() < 1e-10 * scale, (jf, kf, om, out, ref)
+        assert np.abs(out.sum(0)).max() < 1e-10 * scale
+
+
+def _directional_check(mol_of, coords, basis_layout_of, dm, ndir, h, tol, cutoff=1e-14, **kw):
+    """Gradient kernel . v  vs  Richardson central difference of the GPU two-electron energy along v."""
+    import torch
+    from joltqc_amd.pyscf import grad
+    from joltqc_amd.pyscf import jk as jkmod
+
+    def energy(c):
+        mol = mol_of(c)
+        lay = basis_layout_of(mol)
+        vj, vk = jkmod.generate_jk_kernel(lay, cutoff, cutoff)(mol, dm, hermi=1, **kw)
+        return float((dm * (0.5 * vj - 0.25 * vk)).sum())
+
+    mol0 = mol_of(coords)
+    lay0 = basis_layout_of(mol0)
+    fn = grad.generate_jk_energy_per_atom(lay0, cutoff=cutoff)
+    g = _np(fn(mol0, dm, **kw))
+    scale = np.abs(g).max()
+    assert np.abs(g.sum(0)).max() < 1e-9 * scale
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for _ in range(ndir):
+        v = rng.normal(size=coords.shape)
+        v /= np.linalg.norm(v)
+        d1 = (energy(coords + h * v) - energy(coords - h * v)) / (2 * h)
+        d2 = (energy(coords + 2 * h * v) - energy(coords - 2 * h * v)) / (4 * h)
+        fd = (4 * d1 - d2) / 3
+        ana = float((g * v).sum())
+        worst = max(worst, abs(fd - ana) / max(abs(fd), scale * 1e-2))
+        assert abs(fd - ana) < tol * max(abs(fd), scale * 1e-2), (fd, ana)
+    return fn, worst
+
+
+def test_every_class_up_to_g_directional_derivative():
+    """benzene with the artificial s..g basis of the reference's autotuner (generate_fragment.py:97-114): all 140 classes."""
+    import torch
+    from joltqc_amd.constants import tile_width
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    shells = [[0, [8.0, 0.2], [1.6, 0.5], [0.4, 0.4]], [0, [0.15, 1.0]], [1, [4.0, 0.3], [0.9, 0.5], [0.25, 0.4]],
+              [2, [0.8, 1.0]], [3, [0.9, 1.0]], [4, [1.0, 1.0]]]
+    atoms = benzene_atoms()
+    sym = [a[0] for a in atoms]
+    coords = np.array([a[1] for a in atoms]) / 0.52917721092
+    mol_of = lambda c: mole.Mole(atom=[(s, tuple(x)) for s, x in zip(sym, c)], basis={"C": shells, "H": shells}, unit="B")
+    lay_of = lambda m: BasisLayout.from_mol(m, alignment=tile_width)
+    n = mol_of(coords).nao
+    rng = np.random.default_rng(3)
+    c = rng.random((n, 21)) - 0.5
+    dm = torch.from_numpy(c @ c.T / 21).cuda()
+    fn, _ = _directional_check(mol_of, coords, lay_of, dm, 2, 4e-3, 1e-5)
+    assert fn.stats["launches"] >= 140 and fn.quartet_count() > 1e6
+
+
+def test_benzene_tzvpp_long_range_exchange_directional_derivative():
+    import torch
+    from joltqc_amd.constants import tile_width
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    atoms = benzene_atoms()
+    sym = [a[0] for a in atoms]
+    coords = np.array([a[1] for a in atoms]) / 0.52917721092
+    mol_of = lambda c: mole.Mole(atom=[(s, tuple(x)) for s, x in zip(sym, c)], basis="def2-tzvpp", unit="B")
+    lay_of = lambda m: BasisLayout.from_mol(m, alignment=tile_width)
+    n = mol_of(coords).nao
+    rng = np.random.default_rng(4)
+    c = rng.random((n, 21)) - 0.5
+    dm = torch.from_numpy(c @ c.T / 21).cuda()
+    _directional_check(mol_of, coords, lay_of, dm, 2, 4e-3, 1e-5)
+    _directional_check(mol_of, coords, lay_of, dm, 1, 4e-3, 1e-5, omega=0.3)
+
+
+def test_112_atoms_svp_directional_derivative_and_default_cutoff():
+    """Taxol-size stand-in / def2-SVP: gradient at the default screening threshold vs the tight one, one random direction."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from joltqc_amd.constants import tile_width
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import grad
+    from joltqc_amd.pyscf.basis import BasisLayout
+    xyz = mole.read_xyz(os.path.join(ROOT, "joltqc_amd/data/molecules", "0112-elongated-nitrogenous.xyz"))
+    rows = [r.split() for r in xyz.splitlines() if r.strip()]
+    sym = [r[0] for r in rows]
+    coords = np.array([[float(x) for x in r[1:4]] for r in rows]) / 0.52917721092
+    mol_of = lambda c: mole.Mole(atom=[(s, tuple(x)) for s, x in zip(sym, c)], basis="def2-svp", unit="B")
+    lay_of = lambda m: BasisLayout.from_mol(m, alignment=tile_width)
+    mol0 = mol_of(coords)
+    np.random.seed(9)
+    nocc = mol0.nelectron // 2
+    c = np.random.rand(mol0.nao, nocc) - 0.5
+    dm = torch.from_numpy(c @ c.T / nocc).cuda()
+    fn, _ = _directional_check(mol_of, coords, lay_of, dm, 1, 4e-3, 1e-5, cutoff=1e-13)
+    g13 = _np(fn(mol0, dm))
+    g10 = _np(grad.generate_jk_energy_per_atom(lay_of(mol0), cutoff=1e-10)(mol0, dm))
+    assert np.abs(g13 - g10).max() < 1e-6 * np.abs(g13).max()
+
+
+def test_rhf_forces_through_apply_match_finite_differences_of_the_scf_energy():
+    """End to end on H2O / def2-SVP: apply() installs ``_jqc_jk_energy_per_atom``; with the one-electron, overlap and nuclear
+    terms differentiated numerically at FIXED density (cheap CPU integrals) the force along a random displacement equals the
+    finite difference of the converged SCF energy (Hellmann-Feynman + Pulay terms consistent with the SCF that produced D)."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import dense
+    from standin_scf import RHF
+    sym = ["O", "H", "H"]
+    coords = np.array([[0.0, 0.0, 0.1174], [-0.757, 0.0, -0.4696], [0.857, 0.1, -0.4696]]) / 0.52917721092
+    mol_of = lambda c: mole.Mole(atom=[(s, tuple(x)) for s, x in zip(sym, c)], basis="def2-svp", unit="B")
+
+    def int1e(mol):
+        S, T, V = dense.int1e_mol(BasisLayout.from_mol(mol), mol)
+        return T + V, S
+
+    def scf(c):
+        mf = jp.apply(RHF(mol_of(c), int1e=int1e))
+        mf.conv_tol = 1e-12
+        e = mf.kernel()
+        assert mf.converged
+        return e, mf
+
+    e0, mf = scf(coords)
+    mol = mf.mol
+    D = np.asarray(mf.make_rdm1())
+    nocc = mol.nelectron // 2
+    C, eps = np.asarray(mf.mo_coeff), np.asarray(mf.mo_energy)
+    W = 2.0 * (C[:, :nocc] * eps[:nocc]) @ C[:, :nocc].T
+    ejk = mf._jqc_jk_energy_per_atom(mol, D)
+    assert isinstance(ejk, np.ndarray) and ejk.shape == (3, 3)
+    rng = np.random.default_rng(2)
+    v = rng.normal(size=coords.shape)
+    v /= np.linalg.norm(v)
+
+    def one_electron(c):
+        m = mol_of(c)
+        h, S = int1e(m)
+        return float(np.einsum("ij,ji->", D, h)) - float(np.einsum("ij,ji->", W, S)) + m.energy_nuc()
+
+    def richardson(f, h):
+        d1 = (f(coords + h * v) - f(coords - h * v)) / (2 * h)
+        d2 = (f(coords + 2 * h * v) - f(coords - 2 * h * v)) / (4 * h)
+        return (4 * d1 - d2) / 3
+
+    force = richardson(one_electron, 2e-3) + float((ejk * v).sum())
+    fd = richardson(lambda c: scf(c)[0], 4e-3)
+    assert abs(force - fd) < 2e-7, (force, fd)
