@@ -1018,6 +1018,31 @@ int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int
     return 0;
 }
 
+int jqc_dft_xcgrad_ao(const double* coords_d, int ngrids, const double* basis_d, int nbas, int blk0, int nblk,
+                      const uint16_t* shell_list_d, const int32_t* row_of_d, const int32_t* nshl_d, const int32_t* nrow_d,
+                      const int64_t* row_base_d, const double* wv_d, int ndim, int64_t comp_stride, double* ws_d,
+                      int32_t* ao_idx_d, const float* shell_la_d, float* row_la_d, void* stream)
+{
+    if (nblk <= 0) return 0;
+    if (ndim != 1 && ndim != 4) return fail(-1, "XC gradient: ndim must be 1 (LDA) or 4 (GGA)");
+    hipLaunchKernelGGL(xcgrad_ao_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, coords_d, ngrids, basis_d, nbas,
+                       blk0, shell_list_d, row_of_d, nshl_d, nrow_d, (const long long*)row_base_d, wv_d, ndim,
+                       (long long)comp_stride, ws_d, ao_idx_d, shell_la_d, row_la_d);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int jqc_dft_xcgrad(int blk0, int nblk, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
+                   const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, double* gao_d,
+                   const float* row_la_d, float thr, void* stream)
+{
+    if (nblk <= 0) return 0;
+    hipLaunchKernelGGL(xcgrad_mfma_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, nrow_d,
+                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, gao_d, row_la_d, thr);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, const double* coords_d,
              const double* W0p_d, const double* W0_d, const double* K_d, const double* Kp_d, const double* RpW_d,
              int vvngrids, int ngrids, int fp32, void* stream)

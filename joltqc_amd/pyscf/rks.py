@@ -127,7 +127,7 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
             state["ws"] = torch.empty(need, dtype=torch.float64, device=dev)
         return state["ws"]
 
-    def _run(grids, ncomp_ao, log_cutoff, body):
+    def _run(grids, ncomp_ao, log_cutoff, body, eval_ao=None):
         dev = _lib.require_gpu()
         L = _lib.lib()
         soa = gcache.coords(grids, dev)
@@ -156,10 +156,14 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
         for blk0, nblk, base_d, rows, ao_idx, row_la in plans[pkey][1]:
             ws = _workspace(dev, rows, ncomp_ao)
             comp_stride = rows * NG
-            _lib.check(L.jqc_dft_eval_ao(soa.data_ptr(), gcache.ngrids_pad, basis.data_ptr(), layout.nbasis, blk0, nblk,
-                                         shell_list.data_ptr(), row_of.data_ptr(), nshl.data_ptr(), nrow.data_ptr(),
-                                         base_d.data_ptr(), ncomp_ao, comp_stride, ws.data_ptr(), ao_idx.data_ptr(),
-                                         shell_la.data_ptr(), row_la.data_ptr(), stream))
+            if eval_ao is None:
+                _lib.check(L.jqc_dft_eval_ao(soa.data_ptr(), gcache.ngrids_pad, basis.data_ptr(), layout.nbasis, blk0, nblk,
+                                             shell_list.data_ptr(), row_of.data_ptr(), nshl.data_ptr(), nrow.data_ptr(),
+                                             base_d.data_ptr(), ncomp_ao, comp_stride, ws.data_ptr(), ao_idx.data_ptr(),
+                                             shell_la.data_ptr(), row_la.data_ptr(), stream))
+            else:
+                eval_ao(L, soa, basis, blk0, nblk, shell_list, row_of, nshl, nrow, base_d, comp_stride, ws, ao_idx, shell_la,
+                        row_la, stream)
             body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, row_la, stream)
             rows_total += int(rows)
         state["stats"]["ao_rows"] = rows_total
@@ -217,6 +221,53 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
             dist.all_reduce(vmat)                 # the one collective of nr_rks: sum of the ranks' block ranges
         return layout.dm_to_mol(vmat + vmat.T)          # the kernel accumulates T = phi X^T only (reference epilogue A + A^T, :654-655)
 
+    def xcgrad_fun(mol, grids, xctype, dm, wv):
+        """Nuclear gradient [natm, 3] of E_xc at fixed density matrix and fixed grid (no grid response), LDA / GGA, for the
+        weighted potential ``wv[ndim, ngrids]`` = weights x vxc that ``vxc_fun`` takes (the reference has
+        no gradient code and defers to GPU4PySCF).  FP64 throughout; AO pairs below cutoff_fp32 are skipped."""
+        dev = _lib.require_gpu()
+        xctype = xctype.upper()
+        ndim = DIM_BY_XC[xctype]
+        if ndim > 4:
+            raise NotImplementedError("XC gradient kernels cover LDA and GGA; meta-GGA is not built")
+        d = layout.dm_from_mol(_t(dm, dev).reshape(layout.nao_mol, layout.nao_mol))
+        d = (0.5 * (d + d.T)).contiguous()
+        log_dm = math.log(float(d.abs().max().item()) + 1e-200)
+        gcache.coords(grids, dev)
+        w = _t(wv, dev).reshape(ndim, -1)
+        if w.shape[1] != gcache.ngrids_pad:
+            wp = torch.zeros((ndim, gcache.ngrids_pad), dtype=torch.float64, device=dev)
+            wp[:, :w.shape[1]] = w
+            w = wp
+        w = w.contiguous()
+        log_wv = math.log(float(w.abs().max().item()) + 1e-300)
+        gao = torch.zeros((nao, 3), dtype=torch.float64, device=dev)
+
+        def eval_ao(L, soa, basis, blk0, nblk, shell_list, row_of, nshl, nrow, base_d, comp_stride, ws, ao_idx, shell_la, row_la,
+                    stream):
+            _lib.check(L.jqc_dft_xcgrad_ao(soa.data_ptr(), gcache.ngrids_pad, basis.data_ptr(), layout.nbasis, blk0, nblk,
+                                           shell_list.data_ptr(), row_of.data_ptr(), nshl.data_ptr(), nrow.data_ptr(),
+                                           base_d.data_ptr(), w.data_ptr(), ndim, comp_stride, ws.data_ptr(), ao_idx.data_ptr(),
+                                           shell_la.data_ptr(), row_la.data_ptr(), stream))
+
+        def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, row_la, stream):
+            _lib.check(L.jqc_dft_xcgrad(blk0, nblk, nrow.data_ptr(), base_d.data_ptr(), comp_stride, ws.data_ptr(),
+                                        ao_idx.data_ptr(), d.data_ptr(), nao, gao.data_ptr(), row_la.data_ptr(),
+                                        log_cut32 - log_dm - log_wv, stream))
+        _run(grids, 8, log_ao_cutoff - max(log_dm, 0.0) - max(log_wv, 0.0), body, eval_ao)
+        if "ao_atom" not in state:
+            ao_atom = np.repeat(layout.atom_of, np.diff(layout.ao_loc))
+            state["ao_atom"] = torch.from_numpy(ao_atom.astype(np.int64)).to(dev)
+            state["natm"] = int(getattr(mol, "natm", int(layout.atom_of.max()) + 1))
+        out = torch.zeros((state["natm"], 3), dtype=torch.float64, device=dev)
+        out.index_add_(0, state["ao_atom"], gao)
+        if nranks > 1:
+            import torch.distributed as dist
+            dist.all_reduce(out)
+        if isinstance(dm, np.ndarray):
+            return out.cpu().numpy()
+        return out
+
     def _eval_xc(ni, xc_code, rho, xctype, dev):
         """``ni.eval_xc_eff`` (libxc, third party) on the caller's side of the boundary: a plain PySCF NumInt takes and
         returns NumPy arrays, a device-resident one (GPU4PySCF-like, ``_jqc_numpy_boundary`` False) device arrays."""
@@ -258,6 +309,7 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
 
     rho_fun.stats = state["stats"]
     vxc_fun.stats = state["stats"]
+    rks_fun.xcgrad_fun = xcgrad_fun
     return rks_fun, rho_fun, vxc_fun
 
 
@@ -547,6 +599,10 @@ def patch(obj, basis_layout, cutoff_fp32, cutoff_fp64, numpy_boundary, shard=Non
             nlc.calls.update(rho=par.drive_grid(nlc.kernels[0], par.OP_RHO, 1), vxc=par.drive_grid(nlc.kernels[1], par.OP_VXC, 1),
                              sums=par.drive_vv10(lambda o, i, f: vv10_sums(o, i, f, shard)))
     ni.get_rho = generate_get_rho(basis_layout, kernels=kernels)
+    # XC part of the forces (LDA / GGA, no grid response): ``obj._jqc_xc_energy_per_atom(mol, grids, xctype, dm, wv)``.  Unsharded
+    # in a multi-GPU run as well (the worker protocol announces rho / vxc / VV10 calls only)
+    obj._jqc_xc_energy_per_atom = (rks_fun.xcgrad_fun if shard is None or shard[1] == 1 else
+                                   generate_rks_kernel(basis_layout, cutoff_fp32=cutoff_fp32, cutoff_fp64=cutoff_fp64)[0].xcgrad_fun)
     ni.nr_rks = MethodType(rks_fun, ni)
     ni.nr_nlc_vxc = MethodType(nlc, ni)
     ni._jqc_numpy_boundary = numpy_boundary

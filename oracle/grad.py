@@ -135,3 +135,33 @@ def jk_energy_per_atom(layout, dm, j_factor=1.0, k_factor=1.0, omega=None):
             tot += g
         out[atoms[3]] -= tot
     return out
+
+
+# ------------------------------------------------------------------------------------------------ exchange-correlation part
+def xc_linear_energy(layout, grid_coords, dm, wv, xctype="LDA"):
+    """L = sum_g sum_c wv[c, g] rho_c(g): the first-order change of E_xc for the potential wv = weights x vxc; its nuclear
+    derivative at fixed D and fixed grid is the XC gradient without grid response (what GPU4PySCF's `get_vxc` gradient gives
+    with ``grid_response = False``)."""
+    from . import dft
+    rho = dft.eval_rho(layout, grid_coords, dm, xctype)
+    wv = np.asarray(wv, dtype=float).reshape(rho.shape[0], -1)
+    return float((rho * wv).sum())
+
+
+def xc_energy_per_atom_fd(make_layout, coords, grid_coords, dm, wv, xctype="LDA", h=2e-3):
+    """Central differences + one Richardson step of ``xc_linear_energy`` with respect to the nuclear positions."""
+    coords = np.asarray(coords, dtype=np.float64)
+    out = np.zeros_like(coords)
+
+    def central(ia, x, step):
+        c = coords.copy()
+        c[ia, x] += step
+        ep = xc_linear_energy(make_layout(c), grid_coords, dm, wv, xctype)
+        c[ia, x] -= 2 * step
+        em = xc_linear_energy(make_layout(c), grid_coords, dm, wv, xctype)
+        return (ep - em) / (2 * step)
+
+    for ia in range(coords.shape[0]):
+        for x in range(3):
+            out[ia, x] = (4.0 * central(ia, x, h) - central(ia, x, 2 * h)) / 3.0
+    return out

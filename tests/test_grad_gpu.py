@@ -195,3 +195,146 @@ def test_rhf_forces_through_apply_match_finite_differences_of_the_scf_energy():
     force = richardson(one_electron, 2e-3) + float((ejk * v).sum())
     fd = richardson(lambda c: scf(c)[0], 4e-3)
     assert abs(force - fd) < 2e-7, (force, fd)
+
+
+@pytest.mark.parametrize("xctype,cart", [("LDA", False), ("GGA", False), ("GGA", True)])
+def test_xc_gradient_kernels_against_finite_differences_of_the_oracle(xctype, cart):
+    """dE_xc/dR at fixed D and fixed grid (LDA, GGA): the MFMA kernels vs finite differences of the CPU oracle's linearised
+    functional sum_g wv . rho (oracle/dft.py eval_rho), s..f shells, points near and far from the nuclei."""
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import rks
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import grad as G
+    basis = {"O": BASIS["O"] + [[3, [1.1, 1.0]]], "H": BASIS["H"] + [[2, [0.7, 1.0]]]}
+    sym = ["O", "H", "H"]
+    coords = np.array([[0.0, 0.05, -0.1], [0.3, 1.1, 1.45], [-1.2, 0.4, -0.9]])
+    mol_of = lambda c: mole.Mole(atom=[(s, tuple(x)) for s, x in zip(sym, c)], basis=basis, unit="B", cart=cart)
+    lay_of = lambda c: BasisLayout.from_mol(mol_of(c), alignment=1)
+    mol = mol_of(coords)
+    rng = np.random.default_rng(8)
+    ng = 1024
+    pts = coords[rng.integers(0, 3, ng)] + rng.normal(0, 0.9, (ng, 3))
+    pts = pts[np.lexsort(pts.T)]
+    ndim = 1 if xctype == "LDA" else 4
+    wv = rng.normal(0, 1.0, (ndim, ng)) * 0.01
+    n = mol.nao
+    d = rng.random((n, n)) - 0.4
+    dm = d + d.T
+
+    class Gr:
+        pass
+    g = Gr(); g.coords = pts; g.weights = np.ones(ng)
+    rks_fun, _, _ = rks.generate_rks_kernel(lay_of(coords), cutoff_fp64=1e-16, cutoff_fp32=1e-16)
+    out = rks_fun.xcgrad_fun(mol, g, xctype, dm, wv)
+    ref = G.xc_energy_per_atom_fd(lay_of, coords, pts, dm, wv, xctype)
+    assert isinstance(out, np.ndarray) and out.shape == (3, 3)
+    assert np.abs(out - ref).max() < 2e-8 * np.abs(ref).max(), (out, ref)
+
+
+def test_xc_gradient_112_atoms_directional_derivative():
+    """Taxol-size stand-in / def2-SVP on a Becke grid: XC gradient kernels (GGA) vs the directional derivative of
+    sum_g wv . rho computed with the parity-green rho kernels at displaced geometries (size-independent property)."""
+    import torch
+    from joltqc_amd.gto import mole
+    from joltqc_amd.gto.grids import Grids
+    from joltqc_amd.pyscf import rks
+    from joltqc_amd.pyscf.basis import BasisLayout
+    xyz = mole.read_xyz(os.path.join(ROOT, "joltqc_amd/data/molecules", "0112-elongated-nitrogenous.xyz"))
+    rows = [r.split() for r in xyz.splitlines() if r.strip()]
+    sym = [r[0] for r in rows]
+    coords = np.array([[float(x) for x in r[1:4]] for r in rows]) / 0.52917721092
+    mol_of = lambda c: mole.Mole(atom=[(s, tuple(x)) for s, x in zip(sym, c)], basis="def2-svp", unit="B")
+    mol0 = mol_of(coords)
+    gg = Grids(mol0, 20, 6).build()
+    order = rks.arg_group_grids(gg.coords)
+    n = gg.coords.shape[0] // 256 * 256
+
+    class Gr:
+        pass
+    g = Gr(); g.coords = gg.coords[order][:n]; g.weights = gg.weights[order][:n]
+    np.random.seed(9)
+    nocc = mol0.nelectron // 2
+    c = np.random.rand(mol0.nao, nocc) - 0.5
+    dm = torch.from_numpy(c @ c.T / nocc).cuda()
+    rng = np.random.default_rng(1)
+    wv = torch.from_numpy(rng.normal(0, 1.0, (4, n)) * g.weights).cuda()
+
+    def lin(cc):
+        m = mol_of(cc)
+        _, rho_k, _ = rks.generate_rks_kernel(BasisLayout.from_mol(m, alignment=1), cutoff_fp64=1e-15, cutoff_fp32=1e-15)
+        return float((rho_k(m, g, "GGA", dm) * wv).sum())
+
+    rks_fun, _, _ = rks.generate_rks_kernel(BasisLayout.from_mol(mol0, alignment=1), cutoff_fp64=1e-15, cutoff_fp32=1e-15)
+    gx = _np(rks_fun.xcgrad_fun(mol0, g, "GGA", dm, wv))
+    assert gx.shape == (len(sym), 3)
+    v = rng.normal(size=coords.shape)
+    v /= np.linalg.norm(v)
+    h = 2e-3
+    d1 = (lin(coords + h * v) - lin(coords - h * v)) / (2 * h)
+    d2 = (lin(coords + 2 * h * v) - lin(coords - 2 * h * v)) / (4 * h)
+    fd = (4 * d1 - d2) / 3
+    ana = float((gx * v).sum())
+    assert abs(fd - ana) < 1e-6 * max(abs(fd), np.abs(gx).max() * 1e-2), (fd, ana)
+
+
+def test_rks_forces_lda_match_finite_differences_of_the_scf_energy():
+    """RKS (Slater exchange stand-in for libxc) through apply() on H2O / def2-SVP with a grid FIXED in space: J gradient
+    (k_factor 0) + XC gradient kernels + numerically differentiated one-electron / overlap / nuclear terms equal the finite
+    difference of the converged SCF energy along a random displacement."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import dense
+    from standin_scf import RKS, Grids as G, SlaterNumInt
+    sym = ["O", "H", "H"]
+    coords = np.array([[0.0, 0.0, 0.1174], [-0.757, 0.0, -0.4696], [0.857, 0.1, -0.4696]]) / 0.52917721092
+    mol_of = lambda c: mole.Mole(atom=[(s, tuple(x)) for s, x in zip(sym, c)], basis="def2-svp", unit="B")
+    rng = np.random.default_rng(7)
+    pts = coords[rng.integers(0, 3, 8192)] + rng.normal(0, 1.0, (8192, 3))
+    pts = pts[np.lexsort(pts.T)]
+    weights = np.full(8192, 0.003)
+
+    def int1e(mol):
+        S, T, V = dense.int1e_mol(BasisLayout.from_mol(mol), mol)
+        return T + V, S
+
+    cfg = jp.get_default_config()
+    cfg["dft"] = {"cutoff_fp32": 1e-14, "cutoff_fp64": 1e-14}
+
+    def scf(c):
+        m = mol_of(c)
+        h, S = int1e(m)
+        mf = jp.apply(RKS(m, h, S, G(pts, weights)), cfg)
+        mf.conv_tol = 1e-12
+        e = mf.kernel()
+        assert mf.converged
+        return e, mf
+
+    e0, mf = scf(coords)
+    mol = mf.mol
+    D = np.asarray(mf.make_rdm1())
+    nocc = mol.nelectron // 2
+    C, eps = np.asarray(mf.mo_coeff), np.asarray(mf.mo_energy)
+    W = 2.0 * (C[:, :nocc] * eps[:nocc]) @ C[:, :nocc].T
+    ej = mf._jqc_jk_energy_per_atom(mol, D, j_factor=1.0, k_factor=0.0)
+    # potential of the converged density: vrho of Slater exchange, weighted
+    rho = _np(mf._numint.get_rho(mol, D, mf.grids))
+    rho = np.maximum(rho.reshape(-1)[:8192], 0)
+    wv = (4.0 / 3.0 * SlaterNumInt.CX * rho ** (1.0 / 3.0) * weights)[None]
+    exc1 = mf._jqc_xc_energy_per_atom(mol, mf.grids, "LDA", D, wv)
+    v = rng.normal(size=coords.shape)
+    v /= np.linalg.norm(v)
+
+    def one_electron(c):
+        m = mol_of(c)
+        h, S = int1e(m)
+        return float(np.einsum("ij,ji->", D, h)) - float(np.einsum("ij,ji->", W, S)) + m.energy_nuc()
+
+    def richardson(f, h):
+        d1 = (f(coords + h * v) - f(coords - h * v)) / (2 * h)
+        d2 = (f(coords + 2 * h * v) - f(coords - 2 * h * v)) / (4 * h)
+        return (4 * d1 - d2) / 3
+
+    force = richardson(one_electron, 2e-3) + float(((np.asarray(ej) + np.asarray(exc1)) * v).sum())
+    fd = richardson(lambda c: scf(c)[0], 4e-3)
+    assert abs(force - fd) < 5e-7, (force, fd)
