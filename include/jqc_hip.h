@@ -205,13 +205,15 @@ int jqc_dft_eval_ao(const double* coords_d, int ngrids, const double* basis_d, i
                     const float* shell_la_d, float* row_la_d, void* stream);
 /* row_la_d: log estimate of every workspace row (sorted, largest first, per block); AO pairs (a, b) of a block with
  * la_a + la_b above thr64 are contracted in FP64, between thr32 and thr64 in FP32 (MFMA f32), below thr32 not at all
- * (the reference's [cutoff_a, cutoff_b) windows, eval_rho.cu:93-106; thr = log cutoff - log max|D| resp. log max|wv|). */
+ * (the reference's [cutoff_a, cutoff_b) windows, eval_rho.cu:93-106; thr = log cutoff - log max|D| resp. log max|wv|).
+ * order_d (may be NULL): permutation of 0..nblk-1, workgroup b of the launch takes block blk0 + order_d[b] -- the host passes the
+ * blocks by descending AO-row count so that the longest ones do not start last. */
 int jqc_dft_rho(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                 const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, int ndim, double* rho_d,
-                const float* row_la_d, float thr64, float thr32, void* stream);
+                const float* row_la_d, float thr64, float thr32, const int32_t* order_d, void* stream);
 int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                 const double* ws_d, const int32_t* ao_idx_d, const double* wv_d, int ndim, int nao, double* vmat_d,
-                const float* row_la_d, float thr64, float thr32, void* stream);
+                const float* row_la_d, float thr64, float thr32, const int32_t* order_d, void* stream);
 /* Nuclear gradient of E_xc at fixed density and fixed grid (LDA: ndim 1, GGA: ndim 4; SURVEY.md 8(f) row 3 -- no reference
  * kernel: JoltQC leaves gradients to GPU4PySCF, whose `get_vxc`-type gradient drivers these two calls serve).
  * jqc_dft_xcgrad_ao: like jqc_dft_eval_ao with EIGHT workspace components per AO row, [phi, X, d_x phi, d_y phi, d_z phi, H^x,
@@ -224,7 +226,7 @@ int jqc_dft_xcgrad_ao(const double* coords_d, int ngrids, const double* basis_d,
                       int32_t* ao_idx_d, const float* shell_la_d, float* row_la_d, void* stream);
 int jqc_dft_xcgrad(int blk0, int nblk, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                    const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, double* gao_d,
-                   const float* row_la_d, float thr, void* stream);
+                   const float* row_la_d, float thr, const int32_t* order_d, void* stream);
 int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, const double* coords_d,
              const double* W0p_d, const double* W0_d, const double* K_d, const double* Kp_d, const double* RpW_d,
              int vvngrids, int ngrids, int fp32, void* stream);

@@ -992,28 +992,28 @@ int jqc_dft_eval_ao(const double* coords_d, int ngrids, const double* basis_d, i
 
 int jqc_dft_rho(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                 const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, int ndim, double* rho_d,
-                const float* row_la_d, float thr64, float thr32, void* stream)
+                const float* row_la_d, float thr64, float thr32, const int32_t* order_d, void* stream)
 {
     if (nblk <= 0) return 0;
     if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
     if (ndim > 4)
         hipLaunchKernelGGL((rho_mfma_kernel<1, 4>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
-                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32);
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32, order_d);
     else
         hipLaunchKernelGGL((rho_mfma_kernel<4, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
-                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32);
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32, order_d);
     HIP_OK(hipGetLastError());
     return 0;
 }
 
 int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                 const double* ws_d, const int32_t* ao_idx_d, const double* wv_d, int ndim, int nao, double* vmat_d,
-                const float* row_la_d, float thr64, float thr32, void* stream)
+                const float* row_la_d, float thr64, float thr32, const int32_t* order_d, void* stream)
 {
     if (nblk <= 0) return 0;
     if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
     hipLaunchKernelGGL(vxc_mfma_kernel, dim3(nblk), dim3(VXC_THREADS), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
-                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, wv_d, ndim, nao, vmat_d, row_la_d, thr64, thr32);
+                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, wv_d, ndim, nao, vmat_d, row_la_d, thr64, thr32, order_d);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1034,11 +1034,11 @@ int jqc_dft_xcgrad_ao(const double* coords_d, int ngrids, const double* basis_d,
 
 int jqc_dft_xcgrad(int blk0, int nblk, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                    const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, double* gao_d,
-                   const float* row_la_d, float thr, void* stream)
+                   const float* row_la_d, float thr, const int32_t* order_d, void* stream)
 {
     if (nblk <= 0) return 0;
     hipLaunchKernelGGL(xcgrad_mfma_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, nrow_d,
-                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, gao_d, row_la_d, thr);
+                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, gao_d, row_la_d, thr, order_d);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -148,12 +148,17 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
             cap = max(WORKSPACE_BYTES, int(WORKSPACE_FRACTION * torch.cuda.get_device_properties(dev).total_memory))
             plan = []
             for blk0, nblk, base, rows in _batches(nrow_h[b_lo:b_hi], ncomp_ao, cap):
+                # launch order of the contraction kernels: blocks with the most AO rows (work ~ rows^2) first, so that the
+                # longest blocks do not start last (1 452 blocks of 200..1 100 rows on 256 CUs)
+                order = np.argsort(-nrow_h[b_lo + blk0:b_lo + blk0 + nblk], kind="stable").astype(np.int32)
                 plan.append((blk0 + b_lo, nblk, torch.from_numpy(base).to(dev), rows,
-                             torch.empty(rows, dtype=torch.int32, device=dev), torch.empty(rows, dtype=torch.float32, device=dev)))
+                             torch.empty(rows, dtype=torch.int32, device=dev), torch.empty(rows, dtype=torch.float32, device=dev),
+                             torch.from_numpy(order).to(dev)))
             if len(plans) > 8:
                 plans.clear()
             plans[pkey] = (nrow_h, plan)
-        for blk0, nblk, base_d, rows, ao_idx, row_la in plans[pkey][1]:
+        for blk0, nblk, base_d, rows, ao_idx, row_la, order_d in plans[pkey][1]:
+            state["order"] = order_d
             ws = _workspace(dev, rows, ncomp_ao)
             comp_stride = rows * NG
             if eval_ao is None:
@@ -187,7 +192,7 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
             # above through the FP64 one, below nowhere (reference rks.py:446-493, eval_rho.cu:93-106)
             _lib.check(L.jqc_dft_rho(blk0, nblk, gcache.ngrids_pad, nrow.data_ptr(), base_d.data_ptr(), comp_stride,
                                      ws.data_ptr(), ao_idx.data_ptr(), d.data_ptr(), nao, ndim, rho.data_ptr(),
-                                     row_la.data_ptr(), log_cut64 - log_dm, log_cut32 - log_dm, stream))
+                                     row_la.data_ptr(), log_cut64 - log_dm, log_cut32 - log_dm, state["order"].data_ptr(), stream))
         _run(grids, 1 if ndim == 1 else 4, log_ao_cutoff - log_dm, body)
         if nranks > 1:
             import torch.distributed as dist
@@ -214,7 +219,8 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
         def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, row_la, stream):
             _lib.check(L.jqc_dft_vxc(blk0, nblk, gcache.ngrids_pad, nrow.data_ptr(), base_d.data_ptr(), comp_stride,
                                      ws.data_ptr(), ao_idx.data_ptr(), w.data_ptr(), ndim, nao, vmat.data_ptr(),
-                                     row_la.data_ptr(), log_cut64 - log_wv_max, log_cut32 - log_wv_max, stream))
+                                     row_la.data_ptr(), log_cut64 - log_wv_max, log_cut32 - log_wv_max, state["order"].data_ptr(),
+                                     stream))
         _run(grids, 1 if ndim == 1 else 4, log_ao_cutoff - log_wv_max, body)
         if nranks > 1:
             import torch.distributed as dist
@@ -253,7 +259,7 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
         def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, row_la, stream):
             _lib.check(L.jqc_dft_xcgrad(blk0, nblk, nrow.data_ptr(), base_d.data_ptr(), comp_stride, ws.data_ptr(),
                                         ao_idx.data_ptr(), d.data_ptr(), nao, gao.data_ptr(), row_la.data_ptr(),
-                                        log_cut32 - log_dm - log_wv, stream))
+                                        log_cut32 - log_dm - log_wv, state["order"].data_ptr(), stream))
         _run(grids, 8, log_ao_cutoff - max(log_dm, 0.0) - max(log_wv, 0.0), body, eval_ao)
         if "ao_atom" not in state:
             ao_atom = np.repeat(layout.atom_of, np.diff(layout.ao_loc))

@@ -194,3 +194,40 @@ def test_rks_scf_through_apply_matches_cpu_oracle_scf():
     assert mf.converged and ref.converged
     assert abs(e_gpu - e_cpu) < 1e-8, e_gpu - e_cpu
     assert abs(e_default - e_cpu) < 1e-6, e_default - e_cpu
+
+
+def test_build_grids_through_apply_on_a_generated_becke_grid():
+    """A17 (reference rks.py:100-177): apply() replaces ``grids.build``; on first use the object's own generator runs (here the
+    Becke generator of joltqc_amd/gto/grids.py standing in for PySCF's), the result is sorted into 1-Bohr boxes and padded to a
+    multiple of 256 with zero-weight points; the SCF on that grid integrates the density to N_e and a rebuilt grid restarts the
+    incremental caches."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from joltqc_amd.gto.grids import Grids
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from standin_scf import RKS
+    from oracle import dense
+    mol = mole.Mole(atom=H2O, basis="def2-svp")
+    S, T, V = dense.int1e_mol(BasisLayout.from_mol(mol), mol)
+    g = Grids(mol, 45, 14)
+    assert g.coords is None
+    mf = jp.apply(RKS(mol, T + V, S, g))
+    assert hasattr(g, "_jqc_original_build")
+    e = mf.kernel()
+    assert mf.converged and g._jqc_generation == 1
+    n = g.coords.shape[0]
+    assert n % 256 == 0 and n > 4000
+    raw = Grids(mol, 45, 14).build()
+    npad = n - raw.coords.shape[0]
+    assert 0 <= npad < 256 and (g.weights[n - npad:] == 0).all() and abs(g.weights.sum() - raw.weights.sum()) < 1e-10 * raw.weights.sum()
+    # box-sorted: consecutive points share their 1-Bohr box far more often than in the generator's atom-by-atom order
+    box = lambda c: np.floor(c - c.min(0)).astype(int)
+    same = lambda c: float((np.abs(np.diff(box(c), axis=0)).sum(1) == 0).mean())
+    assert same(g.coords[: n - npad]) > same(raw.coords) + 0.1
+    D = np.asarray(mf.make_rdm1())
+    rho = mf._numint.get_rho(mol, D, g)
+    rho = rho.cpu().numpy() if hasattr(rho, "cpu") else np.asarray(rho)
+    assert abs(float((rho[:n] * g.weights).sum()) - mol.nelectron) < 2e-3
+    g.build()                                        # a rebuilt grid bumps the generation; the next SCF restarts its increments
+    assert g._jqc_generation == 2
+    assert abs(mf.kernel() - e) < 1e-9
