@@ -110,6 +110,26 @@ __device__ __forceinline__ void axis_integrals_g(real g0, real c0, real cp, real
     }
 }
 
+// base index ranges of the class (the derivative records below): idx = i * BI + j * BJ + k * BK + l
+constexpr int BK = LL + 1, BJ = (LK + 1) * BK, BI = (LJ + 1) * BJ, GSB = (LI + 1) * BI;
+
+// q[idx] = {g, 2 a_i g(i+1) - i g(i-1), 2 a_j g(j+1) - j g(j-1), 2 a_k g(k+1) - k g(k-1)} from the extended array of one axis
+__device__ __forceinline__ void derivative_records(const real* __restrict__ g, const real ai2, const real aj2, const real ak2,
+                                                   real (*__restrict__ q)[4])
+{
+    for (int i = 0; i <= LI; i++)
+        for (int j = 0; j <= LJ; j++)
+            for (int k = 0; k <= LK; k++)
+                for (int l = 0; l <= LL; l++) {
+                    const int e = i * SI + j * SJ + k * SK + l;
+                    const int b = i * BI + j * BJ + k * BK + l;
+                    q[b][0] = g[e];
+                    q[b][1] = ai2 * g[e + SI] - (i ? i * g[e - SI] : real(0));
+                    q[b][2] = aj2 * g[e + SJ] - (j ? j * g[e - SJ] : real(0));
+                    q[b][3] = ak2 * g[e + SK] - (k ? k * g[e - SK] : real(0));
+                }
+}
+
 __device__ __forceinline__ void quartet_grad(const int nao, const real* __restrict__ basis, const real* __restrict__ dm,
                                              const int n_dm, double* __restrict__ grad, const int* __restrict__ shell_atom,
                                              const real jfac, const real kfac, const real omega, const ushort4 sq,
@@ -224,10 +244,18 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
                 const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
                 const real b01 = real(0.5) * inv_akl * (real(1) - rt_akl);
                 const real b00 = real(0.5) * rt_aa;
-                real gx[GSZ], gy[GSZ], gz[GSZ];
-                axis_integrals_g(ckcl, rpa[0] - rt_aij * rpq[0], rqc[0] + rt_akl * rpq[0], b10, b01, b00, rij[0], rkl[0], gx);
-                axis_integrals_g(gy0, rpa[1] - rt_aij * rpq[1], rqc[1] + rt_akl * rpq[1], b10, b01, b00, rij[1], rkl[1], gy);
-                axis_integrals_g(wt, rpa[2] - rt_aij * rpq[2], rqc[2] + rt_akl * rpq[2], b10, b01, b00, rij[2], rkl[2], gz);
+                // per axis: the 1-D integrals over the class's own index ranges together with their three centre derivatives,
+                // q[idx][0..3] = {g, dg/dA, dg/dB, dg/dC} (one 32-byte record per index: three wide loads per component below)
+                real qx[GSB][4], qy[GSB][4], qz[GSB][4];
+                {
+                    real g[GSZ];
+                    axis_integrals_g(ckcl, rpa[0] - rt_aij * rpq[0], rqc[0] + rt_akl * rpq[0], b10, b01, b00, rij[0], rkl[0], g);
+                    derivative_records(g, ai2, aj2, ak2, qx);
+                    axis_integrals_g(gy0, rpa[1] - rt_aij * rpq[1], rqc[1] + rt_akl * rpq[1], b10, b01, b00, rij[1], rkl[1], g);
+                    derivative_records(g, ai2, aj2, ak2, qy);
+                    axis_integrals_g(wt, rpa[2] - rt_aij * rpq[2], rqc[2] + rt_akl * rpq[2], b10, b01, b00, rij[2], rkl[2], g);
+                    derivative_records(g, ai2, aj2, ak2, qz);
+                }
                 GUNROLL
                 for (int i = 0; i < NFI; i++)
                 GUNROLL
@@ -236,12 +264,9 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
                 for (int k = 0; k < NFK; k++)
                 GUNROLL
                 for (int l = 0; l < NFL; l++) {
-                    const int ix = TI.x[i], iy = TI.y[i], iz = TI.z[i];
-                    const int jx = TJ.x[j], jy = TJ.y[j], jz = TJ.z[j];
-                    const int kx = TK.x[k], ky = TK.y[k], kz = TK.z[k];
-                    const int ax = ix * SI + jx * SJ + kx * SK + TL.x[l];
-                    const int ay = iy * SI + jy * SJ + ky * SK + TL.y[l];
-                    const int az = iz * SI + jz * SJ + kz * SK + TL.z[l];
+                    const int bx = TI.x[i] * BI + TJ.x[j] * BJ + TK.x[k] * BK + TL.x[l];
+                    const int by = TI.y[i] * BI + TJ.y[j] * BJ + TK.y[k] * BK + TL.y[l];
+                    const int bz = TI.z[i] * BI + TJ.z[j] * BJ + TK.z[k] * BK + TL.z[l];
                     real p;
                     if (P_ARRAY) p = P[((i * NFJ + j) * NFK + k) * NFL + l];
                     else {
@@ -250,17 +275,11 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
                             p -= sik[(s * NFI + i) * NFK + k] * sjl[(s * NFJ + j) * NFL + l] +
                                  sil[(s * NFI + i) * NFL + l] * sjk[(s * NFJ + j) * NFK + k];
                     }
-                    const real X = gx[ax], Y = gy[ay], Z = gz[az];
+                    const real X = qx[bx][0], Y = qy[by][0], Z = qz[bz][0];
                     const real pyz = p * Y * Z, pxz = p * X * Z, pxy = p * X * Y;
-                    gA[0] += pyz * (ai2 * gx[ax + SI] - (ix ? ix * gx[ax - SI] : real(0)));
-                    gA[1] += pxz * (ai2 * gy[ay + SI] - (iy ? iy * gy[ay - SI] : real(0)));
-                    gA[2] += pxy * (ai2 * gz[az + SI] - (iz ? iz * gz[az - SI] : real(0)));
-                    gB[0] += pyz * (aj2 * gx[ax + SJ] - (jx ? jx * gx[ax - SJ] : real(0)));
-                    gB[1] += pxz * (aj2 * gy[ay + SJ] - (jy ? jy * gy[ay - SJ] : real(0)));
-                    gB[2] += pxy * (aj2 * gz[az + SJ] - (jz ? jz * gz[az - SJ] : real(0)));
-                    gC[0] += pyz * (ak2 * gx[ax + SK] - (kx ? kx * gx[ax - SK] : real(0)));
-                    gC[1] += pxz * (ak2 * gy[ay + SK] - (ky ? ky * gy[ay - SK] : real(0)));
-                    gC[2] += pxy * (ak2 * gz[az + SK] - (kz ? kz * gz[az - SK] : real(0)));
+                    gA[0] += pyz * qx[bx][1]; gB[0] += pyz * qx[bx][2]; gC[0] += pyz * qx[bx][3];
+                    gA[1] += pxz * qy[by][1]; gB[1] += pxz * qy[by][2]; gC[1] += pxz * qy[by][3];
+                    gA[2] += pxy * qz[bz][1]; gB[2] += pxy * qz[bz][2]; gC[2] += pxy * qz[bz][3];
                 }
             }
         }

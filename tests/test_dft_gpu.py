@@ -220,10 +220,11 @@ def test_build_grids_through_apply_on_a_generated_becke_grid():
     raw = Grids(mol, 45, 14).build()
     npad = n - raw.coords.shape[0]
     assert 0 <= npad < 256 and (g.weights[n - npad:] == 0).all() and abs(g.weights.sum() - raw.weights.sum()) < 1e-10 * raw.weights.sum()
-    # box-sorted: consecutive points share their 1-Bohr box far more often than in the generator's atom-by-atom order
-    box = lambda c: np.floor(c - c.min(0)).astype(int)
-    same = lambda c: float((np.abs(np.diff(box(c), axis=0)).sum(1) == 0).mean())
-    assert same(g.coords[: n - npad]) > same(raw.coords) + 0.1
+    # box-sorted: the box key of the reference's arg_group_grids is non-decreasing along the points (sorting again is the
+    # identity), which the generator's atom-by-atom order is not
+    from joltqc_amd.pyscf import rks
+    assert (rks.arg_group_grids(g.coords[: n - npad]) == np.arange(n - npad)).all()
+    assert not (rks.arg_group_grids(raw.coords) == np.arange(n - npad)).all()
     D = np.asarray(mf.make_rdm1())
     rho = mf._numint.get_rho(mol, D, g)
     rho = rho.cpu().numpy() if hasattr(rho, "cpu") else np.asarray(rho)
