@@ -144,10 +144,11 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
             obj.get_veff = MethodType(_jk.generate_get_veff(), obj)
         # gradient of the two-electron energy at fixed density (the closure does no device work until it is called)
         from . import grad as _grad
-        # (unsharded also in a multi-GPU run: the driver/worker protocol of parallel.py announces J/K and grid calls only, and
-        #  forces are needed once per geometry; `grad.generate_jk_energy_per_atom(layout, shard=(rank, n))` shards when every
-        #  rank calls it)
-        jk_grad = _grad.generate_jk_energy_per_atom(basis_layout_jk, cutoff=min(jk_cutoff_fp32, jk_cutoff_fp64))
+        jk_grad = _grad.generate_jk_energy_per_atom(basis_layout_jk, cutoff=min(jk_cutoff_fp32, jk_cutoff_fp64), shard=shard)
+        if shard is not None:
+            obj._jqc_parallel[_par.OP_GRADJK] = jk_grad            # the quartet queue is dealt to the ranks like the J/K build
+            if shard[0] == 0:
+                jk_grad = _par.drive_grad_jk(jk_grad)
         obj._jqc_jk_energy_per_atom = jk_grad
         if config.get("grad") and _is(obj, "RHF") and not _is(obj, "RKS") and hasattr(obj, "nuc_grad_method") \
                 and not hasattr(obj, "_jqc_original_nuc_grad_method"):

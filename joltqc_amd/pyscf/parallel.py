@@ -1,7 +1,7 @@
 """Multi-GPU driver/worker protocol of the patched mean-field object.
 
 One process per GPU (``torch.distributed``; backend ``nccl`` is RCCL over xGMI).  Rank 0 owns the PySCF object: every
-patched call (``get_jk``, the grid path's ``rho_fun`` / ``vxc_fun``) first broadcasts a small header and its matrix
+patched call (``get_jk``, the grid path's ``rho_fun`` / ``vxc_fun``, the two-electron gradient ``_jqc_jk_energy_per_atom``) first broadcasts a small header and its matrix
 argument (the density matrix or the weighted potential), then every rank evaluates ITS share of the work -- shell-quartet
 task rows for J/K, ranges of 256-point grid blocks for the grid path -- and the partial results meet in ONE all-reduce
 (raw ``[vj; vk]``, ``rho`` or ``vxcmat``).  Ranks > 0 sit in ``serve()`` and mirror the calls:
@@ -15,7 +15,7 @@ The reference has no multi-GPU path (one CuPy device); this replaces nothing the
 """
 import numpy as np
 
-OP_STOP, OP_JK, OP_RHO, OP_VXC, OP_VV10 = 0, 1, 2, 3, 4
+OP_STOP, OP_JK, OP_RHO, OP_VXC, OP_VV10, OP_GRADJK = 0, 1, 2, 3, 4, 5
 _HEADER = 12
 
 
@@ -81,6 +81,25 @@ def drive_jk(get_jk_sharded):
     return get_jk
 
 
+def drive_grad_jk(fn_sharded):
+    """Rank-0 wrapper of a sharded ``jk_energy_per_atom`` (pyscf/grad.py): announce, broadcast the densities, take part; the
+    partial per-atom gradients meet in the closure's all-reduce of natm x 3 doubles."""
+    def jk_energy_per_atom(mol=None, dm=None, j_factor=1.0, k_factor=1.0, omega=None, hermi=1, verbose=None):
+        import torch
+        d = dm if torch.is_tensor(dm) else np.asarray(dm)
+        shape = tuple(d.shape)
+        _bcast_header([OP_GRADJK, len(shape), shape[0] if len(shape) == 3 else 1, shape[-1], float(j_factor), float(k_factor),
+                       float(omega) if omega else 0.0])
+        out = fn_sharded(mol, _bcast_matrix(d, shape), j_factor, k_factor, omega, hermi, verbose)
+        if isinstance(dm, np.ndarray) and torch.is_tensor(out):
+            out = out.cpu().numpy()
+        return out
+    for k in ("stats", "quartet_count", "layout"):
+        if hasattr(fn_sharded, k):
+            setattr(jk_energy_per_atom, k, getattr(fn_sharded, k))
+    return jk_energy_per_atom
+
+
 def drive_grid(fn, op, which=0):
     """Rank-0 wrapper of the sharded ``rho_fun`` / ``vxc_fun``: broadcast (xc type, which grid, matrix), then take part.
     ``which``: 0 = the object's ``grids``, 1 = its ``nlcgrids``."""
@@ -135,6 +154,10 @@ def serve(handlers):
             mat = _bcast_matrix(None, (n0, n1) if ndim == 2 else (n1,))
             fn, mol, grids = handlers[op][int(h[5])]
             fn(mol, grids() if callable(grids) else grids, XC[int(h[4])], mat)
+        elif op == OP_GRADJK:
+            ndim, n_dm, nao = int(h[1]), int(h[2]), int(h[3])
+            dm = _bcast_matrix(None, (n_dm, nao, nao) if ndim == 3 else (nao, nao))
+            handlers[OP_GRADJK](None, dm, h[4], h[5], h[6] if h[6] > 0 else None)
         elif op == OP_VV10:
             outer = _bcast_matrix(None, (int(h[1]), int(h[2])))
             inner = _bcast_matrix(None, (int(h[3]), int(h[4])))

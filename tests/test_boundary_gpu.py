@@ -225,6 +225,9 @@ def _parallel_worker(rank, world, port, q):
     if rank == 0:
         out["e_rhf"] = mf.kernel()
         out["n_rhf"] = mf.get_jk.quartet_counts()[0]
+        out["dm"] = np.asarray(mf.make_rdm1())
+        out["ejk"] = mf._jqc_jk_energy_per_atom(mol, out["dm"])                       # forces: the quartet queue is shared too
+        out["n_grad"] = mf._jqc_jk_energy_per_atom.quartet_count()
         par.stop()
         out["e_rks"] = ks.kernel()
         out["blocks"] = ks._numint.nr_rks.__func__.gcache.ngrids_pad // 256
@@ -233,6 +236,7 @@ def _parallel_worker(rank, world, port, q):
     else:
         n1 = par.serve(mf)
         out["n_rhf"] = mf._jqc_parallel[par.OP_JK].quartet_counts()[0]
+        out["n_grad"] = mf._jqc_parallel[par.OP_GRADJK].quartet_count()
         n2 = par.serve(ks)
         out["calls"] = (n1, n2)
         out["range"] = ks._jqc_parallel[par.OP_RHO][0][0].stats.get("block_range")
@@ -273,5 +277,8 @@ def test_two_ranks_through_apply_rank0_owns_the_object():
     assert abs(res[0]["e_rhf"] - e_rhf) < 1e-9 and abs(res[0]["e_rks"] - e_rks) < 1e-9
     assert res[0]["n_rhf"] + res[1]["n_rhf"] == n_all and min(res[0]["n_rhf"], res[1]["n_rhf"]) > 0
     assert res[1]["calls"][0] > 5 and res[1]["calls"][1] > 10            # every SCF iteration was mirrored
+    ejk = mf._jqc_jk_energy_per_atom(mol, res[0]["dm"])
+    assert np.abs(res[0]["ejk"] - ejk).max() < 1e-9 * np.abs(ejk).max()
+    assert res[0]["n_grad"] + res[1]["n_grad"] == mf._jqc_jk_energy_per_atom.quartet_count() and min(res[0]["n_grad"], res[1]["n_grad"]) > 0
     b0, b1 = res[1]["range"]
     assert 0 < b0 < b1 == res[0]["blocks"]                                  # rank 1 took the upper range of the grid blocks

@@ -41,6 +41,12 @@ def _worker(rank, world, port, q):
         dist.all_reduce(out)
         return out
 
+    def fake_grad(mol, dm, j_factor=1.0, k_factor=1.0, omega=None, hermi=1, verbose=None):
+        out = torch.as_tensor(dm, dtype=torch.float64).sum() * (rank + 1.0) * j_factor * torch.ones((4, 3), dtype=torch.float64)
+        dist.all_reduce(out)
+        log.append(("grad", float(j_factor), float(k_factor), omega, tuple(dm.shape)))
+        return out
+
     assert par.world() == (rank, world)
     if rank == 0:
         get_jk = par.drive_jk(fake_jk)
@@ -53,11 +59,12 @@ def _worker(rank, world, port, q):
         rho = par.drive_grid(fake_grid, par.OP_RHO, 0)(None, "G0", "GGA", np.ones((4, 7)))
         vx = par.drive_grid(fake_grid, par.OP_VXC, 1)(None, "G1", "MGGA", np.ones(6))
         sm = par.drive_vv10(fake_sums)(torch.arange(40, dtype=torch.float64).reshape(5, 8), torch.ones(6, 4, dtype=torch.float64), True)
+        gr = par.drive_grad_jk(fake_grad)(None, dm3, j_factor=0.5, k_factor=0.25, omega=0.2)
         par.stop()
-        q.put((0, dict(vj=vj, vk=vk, vj3=vj3, vk3=vk3, rho=rho.numpy(), vx=vx.numpy(), sm=sm.numpy(), dm=dm, dm3=dm3), log))
+        q.put((0, dict(vj=vj, vk=vk, vj3=vj3, vk3=vk3, rho=rho.numpy(), vx=vx.numpy(), sm=sm.numpy(), dm=dm, dm3=dm3, gr=gr), log))
     else:
         n = par.serve({par.OP_JK: fake_jk, par.OP_RHO: {0: (fake_grid, None, lambda: "G0")}, par.OP_VXC: {1: (fake_grid, None, "G1")},
-                       par.OP_VV10: fake_sums})
+                       par.OP_VV10: fake_sums, par.OP_GRADJK: fake_grad})
         q.put((rank, n, log))
     dist.destroy_process_group()
 
@@ -75,12 +82,13 @@ def test_driver_and_worker_mirror_every_call():
         p.join(30)
         assert p.exitcode == 0
     (_, r0, log0), (_, ncalls, log1) = res
-    assert ncalls == 5 and log0 == log1                      # same calls, same arguments, same order on both ranks
+    assert ncalls == 6 and log0 == log1                      # same calls, same arguments, same order on both ranks
     assert isinstance(r0["vj"], np.ndarray) and np.allclose(r0["vj"], 3.0 * r0["dm"]) and np.allclose(r0["vk"], 6.0 * r0["dm"])
     assert r0["vj3"] == 0 and np.allclose(r0["vk3"], 6.0 * r0["dm3"]) and log1[1] == ("jk", 0, False, True, 0.3, (2, 5, 5))
     assert np.allclose(r0["rho"], 28.0 * 3.0) and np.allclose(r0["vx"], 6.0 * 3.0)
     assert log1[2] == ("grid", "GGA", "G0", (4, 7)) and log1[3] == ("grid", "MGGA", "G1", (6,))
     assert np.allclose(r0["sm"], np.tile(np.arange(24, 32) * 4.0, (3, 1)))
+    assert isinstance(r0["gr"], np.ndarray) and np.allclose(r0["gr"], 1.5 * r0["dm3"].sum()) and log1[-1] == ("grad", 0.5, 0.25, 0.2, (2, 5, 5))
 
 
 def test_split_blocks_is_a_balanced_partition():
