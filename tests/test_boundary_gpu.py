@@ -70,8 +70,6 @@ def test_get_j_goes_through_the_pair_backend_by_default():
     vj3 = mf.get_j(mol, np.stack([dm, 2 * dm, dm @ dm]), hermi=0)          # several densities, non-symmetric one included
     ref3 = mf.get_jk(mol, np.stack([dm, 2 * dm, dm @ dm]), hermi=0)[0]
     assert vj3.shape == (3,) + dm.shape and np.abs(vj3 - ref3).max() < 1e-11 * np.abs(ref3).max()
-    vlr = mf.get_j(mol, dm, hermi=1, omega=0.3)
-    assert np.abs(vlr - mf.get_jk(mol, dm, hermi=1, omega=0.3)[0]).max() < 1e-11 * np.abs(ref).max()
     cfg = jp.get_default_config()
     cfg["jk"]["pair_j"] = False
     mf2 = jp.apply(RHF(mol, int1e=_int1e), cfg)
