@@ -632,14 +632,38 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
             // Builds that spill vector registers to scratch also re-read the staging pointers from the kernarg segment
             // (KARG_RELOAD in jk_tile.hip: ~45 fewer SGPRs spilled to VGPR lanes); builds without scratch keep the
             // pointers in SGPRs, which is 2-20 % faster for the short-iteration classes.  See DESIGN.md section 3.1.
-            std::string code;
-            d.push_back("-DKARG_RELOAD=0");
-            int rc = compile_code(src, d, code);
-            if (rc) return rc;
-            if (scratch_bytes(code) != 0) {
-                d.back() = "-DKARG_RELOAD=1";
-                rc = compile_code(src, d, code);
+            auto build = [&](std::vector<std::string> dd, std::string& code) -> int {
+                dd.push_back("-DKARG_RELOAD=0");
+                int rc = compile_code(src, dd, code);
                 if (rc) return rc;
+                if (scratch_bytes(code) != 0) {
+                    dd.back() = "-DKARG_RELOAD=1";
+                    rc = compile_code(src, dd, code);
+                }
+                return rc;
+            };
+            std::string code;
+            int rc = build(d, code);
+            if (rc) return rc;
+            // The scheme table is tuned on the J+K builds.  The J-only / K-only build of a lane-per-quartet variant has fewer LDS
+            // tiles, so the compiler may size its register budget for more workgroups per CU than the variant was tuned for
+            // and spill (> 1 KB per lane, 4-5 x slower: profiles/r02_class_profile_j_only_*): if the build spills more than 512 B, the same
+            // variant is rebuilt for fewer waves per SIMD and the build with the least scratch is kept.  (Lane-per-quartet
+            // kernels only: 512-register builds of that mode are the tuned form of the large classes; the row-lane
+            // mode never goes below two waves per SIMD)
+            if (algo == JQC_ALGO_TILE1Q && !(do_j && do_k) && scratch_bytes(code) > 512) {
+                long best = scratch_bytes(code);
+                for (int minw = (v_minw ? v_minw : 2) - 1; minw >= 1 && best > 0; minw--) {
+                    std::vector<std::string> dd = d;
+                    bool replaced = false;
+                    for (auto& x : dd)
+                        if (x.rfind("-DMINW=", 0) == 0) { x = "-DMINW=" + std::to_string(minw); replaced = true; }
+                    if (!replaced) dd.push_back("-DMINW=" + std::to_string(minw));
+                    std::string c2;
+                    rc = build(dd, c2);
+                    if (rc) return rc;
+                    if ((long)scratch_bytes(c2) < best) { best = scratch_bytes(c2); code.swap(c2); }
+                }
             }
             rc = write_code(code, out);
             if (rc) return rc;

@@ -74,6 +74,15 @@ def test_112_atoms_full_size_properties(basis):
     assert r["lin_J"] < 1e-11 and r["lin_K"] < 1e-11, r
     assert r["lr_J"] < 1e-11 and r["lr_K"] < 1e-11 and r["lr_Kmax"] > 1e-3, r
     assert r["mixed_J"] < 1e-7 and r["mixed_K"] < 1e-7, r
+    # the J-only and K-only builds of the main-table variants (their own code objects: other register budgets, and for the
+    # lane-per-quartet variants the least-scratch build of jqc_gen_jk_kernel) against the J and K of the J+K build
+    from joltqc_amd.pyscf import jk as jkmod
+    g = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
+    vj, vk = (x.clone() for x in g(mol, dm, hermi=1))
+    vj1 = g(mol, dm, hermi=1, with_k=False)[0]
+    vk1 = g(mol, dm, hermi=1, with_j=False)[1]
+    sc = float(max(vj.abs().max(), vk.abs().max()))
+    assert float((vj1 - vj).abs().max()) < 1e-11 * sc and float((vk1 - vk).abs().max()) < 1e-11 * sc
 
 
 @pytest.mark.parametrize("omega", [0.0, 0.3])

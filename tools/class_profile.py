@@ -1,5 +1,5 @@
 """Per-class timing of the tiled J/K kernels (serialised on one stream) vs the FLOP model.
-usage: JQC_STREAMS=1 python tools/class_profile.py [benzene|<xyz name>] [basis]"""
+usage: JQC_STREAMS=1 python tools/class_profile.py [benzene|<xyz name>]        (JQC_PROFILE_MODE=j | k: J-only / K-only kernels)"""
 import os, sys, json
 os.environ.setdefault("JQC_STREAMS", "1")
 import numpy as np, torch
@@ -15,10 +15,12 @@ lay = BasisLayout.from_mol(mol, alignment=tile_width)
 np.random.seed(9)
 dm = np.random.rand(mol.nao, mol.nao); dm = torch.from_numpy(dm @ dm.T).cuda()
 g = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
-for _ in range(2): g(mol, dm, hermi=1)
+mode = os.environ.get("JQC_PROFILE_MODE", "jk")
+kw = {"with_j": "j" in mode, "with_k": "k" in mode}
+for _ in range(2): g(mol, dm, hermi=1, **kw)
 torch.cuda.synchronize()
 g.set_probe("all")
-for _ in range(3): g(mol, dm, hermi=1)
+for _ in range(3): g(mol, dm, hermi=1, **kw)
 torch.cuda.synchronize()
 n64, n32, per = g.quartet_counts()
 fl, cnt = {}, {}
