@@ -214,10 +214,11 @@ int jqc_dft_rho(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int
 int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                 const double* ws_d, const int32_t* ao_idx_d, const double* wv_d, int ndim, int nao, double* vmat_d,
                 const float* row_la_d, float thr64, float thr32, const int32_t* order_d, void* stream);
-/* Nuclear gradient of E_xc at fixed density and fixed grid (LDA: ndim 1, GGA: ndim 4; SURVEY.md 8(f) row 3 -- no reference
+/* Nuclear gradient of E_xc at fixed density and fixed grid (LDA: ndim 1, GGA: ndim 4, meta-GGA: ndim 5; SURVEY.md 8(f) row 3 -- no reference
  * kernel: JoltQC leaves gradients to GPU4PySCF, whose `get_vxc`-type gradient drivers these two calls serve).
  * jqc_dft_xcgrad_ao: like jqc_dft_eval_ao with EIGHT workspace components per AO row, [phi, X, d_x phi, d_y phi, d_z phi, H^x,
- *   H^y, H^z], X = wv0 phi + sum_y wv_y d_y phi, H^x = sum_y wv_y d_x d_y phi, wv_d[ndim][ngrids] = weights x vxc.
+ *   H^y, H^z], X = wv0 phi + sum_y wv_y d_y phi, H^x = sum_y wv_y d_x d_y phi, wv_d[ndim][ngrids] = weights x vxc; ndim = 5
+ *   (meta-GGA): FOURTEEN components, the six added ones T_uv = 1/2 wv4 d_u d_v phi (xx, xy, xz, yy, yz, zz).
  * jqc_dft_xcgrad: gao_d[ao][3] += -2 sum_g (d_x phi_a (D X)_a + H^x_a (D phi)_a) for the AO rows of blocks [blk0, blk0+nblk);
  *   AO pairs with la_a + la_b <= thr are skipped; FP64 MFMA.  The caller sums AOs into atoms. */
 int jqc_dft_xcgrad_ao(const double* coords_d, int ngrids, const double* basis_d, int nbas, int blk0, int nblk,
@@ -226,7 +227,7 @@ int jqc_dft_xcgrad_ao(const double* coords_d, int ngrids, const double* basis_d,
                       int32_t* ao_idx_d, const float* shell_la_d, float* row_la_d, void* stream);
 int jqc_dft_xcgrad(int blk0, int nblk, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                    const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, double* gao_d,
-                   const float* row_la_d, float thr, const int32_t* order_d, void* stream);
+                   const float* row_la_d, float thr, const int32_t* order_d, int ndim, void* stream);
 int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, const double* coords_d,
              const double* W0p_d, const double* W0_d, const double* K_d, const double* Kp_d, const double* RpW_d,
              int vvngrids, int ngrids, int fp32, void* stream);

@@ -82,7 +82,7 @@ def lib():
         L.jqc_dft_rho.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp, f32, f32, vp, vp]
         L.jqc_dft_vxc.argtypes = [i32, i32, i32, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp, f32, f32, vp, vp]
         L.jqc_dft_xcgrad_ao.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp]
-        L.jqc_dft_xcgrad.argtypes = [i32, i32, vp, vp, i64, vp, vp, vp, i32, vp, vp, f32, vp, vp]
+        L.jqc_dft_xcgrad.argtypes = [i32, i32, vp, vp, i64, vp, vp, vp, i32, vp, vp, f32, vp, i32, vp]
         L.jqc_vv10.argtypes = [vp] * 10 + [i32, i32, i32, vp]
         from ..constants import TILE_WIDTHS
         L.jqc_set_tile_widths.argtypes = [c.POINTER(c.c_int)]

@@ -1048,7 +1048,7 @@ int jqc_dft_xcgrad_ao(const double* coords_d, int ngrids, const double* basis_d,
                       int32_t* ao_idx_d, const float* shell_la_d, float* row_la_d, void* stream)
 {
     if (nblk <= 0) return 0;
-    if (ndim != 1 && ndim != 4) return fail(-1, "XC gradient: ndim must be 1 (LDA) or 4 (GGA)");
+    if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "XC gradient: ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
     hipLaunchKernelGGL(xcgrad_ao_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, coords_d, ngrids, basis_d, nbas,
                        blk0, shell_list_d, row_of_d, nshl_d, nrow_d, (const long long*)row_base_d, wv_d, ndim,
                        (long long)comp_stride, ws_d, ao_idx_d, shell_la_d, row_la_d);
@@ -1058,11 +1058,15 @@ int jqc_dft_xcgrad_ao(const double* coords_d, int ngrids, const double* basis_d,
 
 int jqc_dft_xcgrad(int blk0, int nblk, const int32_t* nrow_d, const int64_t* row_base_d, int64_t comp_stride,
                    const double* ws_d, const int32_t* ao_idx_d, const double* dm_d, int nao, double* gao_d,
-                   const float* row_la_d, float thr, const int32_t* order_d, void* stream)
+                   const float* row_la_d, float thr, const int32_t* order_d, int ndim, void* stream)
 {
     if (nblk <= 0) return 0;
-    hipLaunchKernelGGL(xcgrad_mfma_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, nrow_d,
-                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, gao_d, row_la_d, thr, order_d);
+    if (ndim > 4)
+        hipLaunchKernelGGL((xcgrad_mfma_kernel<5, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, nrow_d,
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, gao_d, row_la_d, thr, order_d);
+    else
+        hipLaunchKernelGGL((xcgrad_mfma_kernel<2, 2>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, nrow_d,
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, gao_d, row_la_d, thr, order_d);
     HIP_OK(hipGetLastError());
     return 0;
 }

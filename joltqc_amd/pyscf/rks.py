@@ -229,13 +229,11 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
 
     def xcgrad_fun(mol, grids, xctype, dm, wv):
         """Nuclear gradient [natm, 3] of E_xc at fixed density matrix and fixed grid (no grid response), LDA / GGA, for the
-        weighted potential ``wv[ndim, ngrids]`` = weights x vxc that ``vxc_fun`` takes (the reference has
+        weighted potential ``wv[ndim, ngrids]`` = weights x vxc that ``vxc_fun`` takes, ndim 1 / 4 / 5 (the reference has
         no gradient code and defers to GPU4PySCF).  FP64 throughout; AO pairs below cutoff_fp32 are skipped."""
         dev = _lib.require_gpu()
         xctype = xctype.upper()
         ndim = DIM_BY_XC[xctype]
-        if ndim > 4:
-            raise NotImplementedError("XC gradient kernels cover LDA and GGA; meta-GGA is not built")
         d = layout.dm_from_mol(_t(dm, dev).reshape(layout.nao_mol, layout.nao_mol))
         d = (0.5 * (d + d.T)).contiguous()
         log_dm = math.log(float(d.abs().max().item()) + 1e-200)
@@ -259,8 +257,8 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
         def body(L, blk0, nblk, nrow, base_d, comp_stride, ws, ao_idx, row_la, stream):
             _lib.check(L.jqc_dft_xcgrad(blk0, nblk, nrow.data_ptr(), base_d.data_ptr(), comp_stride, ws.data_ptr(),
                                         ao_idx.data_ptr(), d.data_ptr(), nao, gao.data_ptr(), row_la.data_ptr(),
-                                        log_cut32 - log_dm - log_wv, state["order"].data_ptr(), stream))
-        _run(grids, 8, log_ao_cutoff - max(log_dm, 0.0) - max(log_wv, 0.0), body, eval_ao)
+                                        log_cut32 - log_dm - log_wv, state["order"].data_ptr(), ndim, stream))
+        _run(grids, 14 if ndim > 4 else 8, log_ao_cutoff - max(log_dm, 0.0) - max(log_wv, 0.0), body, eval_ao)
         if "ao_atom" not in state:
             ao_atom = np.repeat(layout.atom_of, np.diff(layout.ao_loc))
             state["ao_atom"] = torch.from_numpy(ao_atom.astype(np.int64)).to(dev)

@@ -197,10 +197,11 @@ def test_rhf_forces_through_apply_match_finite_differences_of_the_scf_energy():
     assert abs(force - fd) < 2e-7, (force, fd)
 
 
-@pytest.mark.parametrize("xctype,cart", [("LDA", False), ("GGA", False), ("GGA", True)])
+@pytest.mark.parametrize("xctype,cart", [("LDA", False), ("GGA", False), ("GGA", True), ("MGGA", False), ("MGGA", True)])
 def test_xc_gradient_kernels_against_finite_differences_of_the_oracle(xctype, cart):
-    """dE_xc/dR at fixed D and fixed grid (LDA, GGA): the MFMA kernels vs finite differences of the CPU oracle's linearised
-    functional sum_g wv . rho (oracle/dft.py eval_rho), s..f shells, points near and far from the nuclei."""
+    """dE_xc/dR at fixed D and fixed grid (LDA, GGA, meta-GGA): the MFMA kernels vs finite differences of the CPU oracle's
+    linearised functional sum_g wv . (rho, grad rho, tau) (oracle/dft.py eval_rho), s..f shells, points near and far from the
+    nuclei."""
     from joltqc_amd.gto import mole
     from joltqc_amd.pyscf import rks
     from joltqc_amd.pyscf.basis import BasisLayout
@@ -215,7 +216,7 @@ def test_xc_gradient_kernels_against_finite_differences_of_the_oracle(xctype, ca
     ng = 1024
     pts = coords[rng.integers(0, 3, ng)] + rng.normal(0, 0.9, (ng, 3))
     pts = pts[np.lexsort(pts.T)]
-    ndim = 1 if xctype == "LDA" else 4
+    ndim = {"LDA": 1, "GGA": 4, "MGGA": 5}[xctype]
     wv = rng.normal(0, 1.0, (ndim, ng)) * 0.01
     n = mol.nao
     d = rng.random((n, n)) - 0.4
