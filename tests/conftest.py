@@ -32,3 +32,15 @@ def benzene_atoms():
         out.append(("C", (rc * np.cos(t), rc * np.sin(t), 0.0)))
         out.append(("H", (rh * np.cos(t), rh * np.sin(t), 0.0)))
     return out
+
+
+# One basis written twice: with general contractions (several coefficient columns per primitive set, 4-5 primitives per
+# contraction: the patterns of 6-31G / cc-pVDZ / cc-pVTZ in the reference's tests/test_basis_sets_jk.py) and as the equivalent
+# segmented shells.  Same AO set in the same order, so every matrix must agree between the two definitions.
+GENERAL_BASIS = {"O": [[0, [12.0, 0.10, -0.03], [2.5, 0.45, -0.12], [0.7, 0.50, 0.30], [0.25, 0.10, 0.60], [0.09, 0.0, 0.35]],
+                       [1, [3.0, 0.3, 0.1], [0.8, 0.5, 0.2], [0.2, 0.4, 0.9]], [2, [0.9, 1.0]]],
+                 "H": [[0, [5.0, 0.15, 0.0], [1.0, 0.6, 0.1], [0.2, 0.4, 1.0]], [1, [0.7, 1.0]]]}
+SEGMENTED_BASIS = {"O": [[0, [12.0, 0.10], [2.5, 0.45], [0.7, 0.50], [0.25, 0.10]],
+                         [0, [12.0, -0.03], [2.5, -0.12], [0.7, 0.30], [0.25, 0.60], [0.09, 0.35]],
+                         [1, [3.0, 0.3], [0.8, 0.5], [0.2, 0.4]], [1, [3.0, 0.1], [0.8, 0.2], [0.2, 0.9]], [2, [0.9, 1.0]]],
+                   "H": [[0, [5.0, 0.15], [1.0, 0.6], [0.2, 0.4]], [0, [1.0, 0.1], [0.2, 1.0]], [1, [0.7, 1.0]]]}

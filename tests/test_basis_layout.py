@@ -85,3 +85,24 @@ def test_cart2sph_known_values():
     for l in range(2, 5):
         c = cart2sph_l(l)
         assert c.shape == ((l + 1) * (l + 2) // 2, 2 * l + 1)
+
+
+@pytest.mark.parametrize("cart", [False, True])
+def test_general_contractions_are_decontracted_and_split(cart):
+    """nctr > 1 shells and contractions of 4-5 primitives (reference split_basis, basis.py:678-837; the patterns its
+    tests/test_basis_sets_jk.py runs through with 6-31G / cc-pVDZ / cc-pVTZ): the layout of the generally contracted basis gives
+    the same overlap and the same J/K (CPU oracle) as the same functions written as segmented shells."""
+    from conftest import GENERAL_BASIS, SEGMENTED_BASIS
+    from oracle import dense
+    m1 = mole.Mole(atom=H2O, basis=GENERAL_BASIS, cart=cart)
+    m2 = mole.Mole(atom=H2O, basis=SEGMENTED_BASIS, cart=cart)
+    assert m1.nao == m2.nao and (np.asarray(m1._bas)[:, 3] > 1).any()                 # general contractions present
+    l1, l2 = BasisLayout.from_mol(m1), BasisLayout.from_mol(m2)
+    assert l1.nprims.max() <= NPRIM_MAX and l2.nprims.max() <= NPRIM_MAX
+    s1, s2 = dense.int1e_mol(l1, m1)[0], dense.int1e_mol(l2, m2)[0]
+    assert np.abs(s1 - s2).max() < 1e-13
+    rng = np.random.default_rng(1)
+    d = rng.random((m1.nao, m1.nao))
+    d = d + d.T
+    (j1, k1), (j2, k2) = dense.get_jk(l1, d, 1), dense.get_jk(l2, d, 1)
+    assert np.abs(j1 - j2).max() < 1e-12 * np.abs(j1).max() and np.abs(k1 - k2).max() < 1e-12 * np.abs(k1).max()

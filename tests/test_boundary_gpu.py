@@ -104,6 +104,36 @@ def test_reset_and_scanner_follow_a_geometry_change():
     assert abs(scanner(mol1) - e1_ref) < 1e-8
 
 
+def test_rks_reset_reapplies_once_per_reset_without_recursion():
+    """Reference tests/test_geom_opt.py::test_reset_rks_object / test_reset_without_recursion: an RKS object is re-patched by
+    every reset (new layouts, grid caches restarted), the reset wrapper is installed once however often it runs, and the energy
+    after reset(mol2) equals a freshly applied object's."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from standin_scf import RKS, Grids as G
+    mol1 = mole.Mole(atom=H2O, basis="def2-svp")
+    mol2 = mole.Mole(atom=H2O_STRETCHED, basis="def2-svp")
+    rng = np.random.default_rng(7)
+    at = mol1.atom_coords()
+    coords = at[rng.integers(0, 3, 4096)] + rng.normal(0, 1.0, (4096, 3))
+    coords = coords[np.lexsort(coords.T)]
+    w = np.full(4096, 0.005)
+
+    def fresh(mol):
+        h, S = _int1e(mol)
+        return jp.apply(RKS(mol, h, S, G(coords, w), int1e=_int1e))
+
+    ks = fresh(mol1)
+    e1 = ks.kernel()
+    original = ks._jqc_original_reset
+    for _ in range(4):                                   # repeated resets: one wrapper, no growing call chain
+        assert ks.reset(mol2) is ks and ks._joltqc_applied and ks._jqc_original_reset is original
+    e2 = ks.kernel()
+    assert abs(e2 - fresh(mol2).kernel()) < 1e-9 and abs(e1 - e2) > 1e-5
+    ks.reset(mol1)
+    assert abs(ks.kernel() - e1) < 1e-9
+
+
 class _RSHNumInt:
     """libxc stand-in for a range-separated hybrid with VV10 (the wB97M-V branch structure): Slater exchange as the
     semilocal part, omega = 0.3, alpha = 1.0, hyb = 0.2, one NLC term (b, C) = (6.0, 0.01)."""

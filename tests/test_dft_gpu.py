@@ -232,3 +232,25 @@ def test_build_grids_through_apply_on_a_generated_becke_grid():
     g.build()                                        # a rebuilt grid bumps the generation; the next SCF restarts its increments
     assert g._jqc_generation == 2
     assert abs(mf.kernel() - e) < 1e-9
+
+
+@pytest.mark.parametrize("cart", [True, False])
+def test_rho_and_vxc_general_contraction_basis(cart):
+    """Reference tests/test_basis_sets_dft.py (6-31G ... cc-pVTZ: general contractions): rho / vxc (GGA) of a generally contracted
+    basis on the GPU against the oracle evaluated on the segmented spelling of the same functions."""
+    from conftest import GENERAL_BASIS, SEGMENTED_BASIS
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import dft
+    mol, lay, grids, rho_k, vxc_k = _setup(H2O, GENERAL_BASIS, cart, 1536)
+    lay2 = BasisLayout.from_mol(mole.Mole(atom=H2O, basis=SEGMENTED_BASIS, cart=cart), alignment=1)
+    np.random.seed(9)
+    dm = np.random.rand(mol.nao, mol.nao)
+    dm = dm @ dm.T
+    rho = rho_k(mol, grids, "GGA", dm).cpu().numpy()
+    ref = dft.eval_rho(lay2, grids.coords, dm, "GGA")
+    assert np.abs(rho - ref).max() < 1e-9 * np.abs(ref).max()
+    wv = np.random.rand(4, 1536)
+    v = vxc_k(mol, grids, "GGA", wv).cpu().numpy()
+    vref = dft.eval_vxc(lay2, grids.coords, wv, "GGA")
+    assert np.abs(v - vref).max() < 1e-9 * np.abs(vref).max()

@@ -329,3 +329,50 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     finally:
         os.environ.pop("JQC_ONLY_CLASS", None)
     assert nclass == 140 and not bad, bad
+
+
+@pytest.mark.parametrize("cart", [False, True])
+def test_general_contraction_basis_against_the_oracle(cart):
+    """Reference tests/test_basis_sets_jk.py (6-31G, cc-pVDZ, cc-pVTZ: general contractions, 4-8 primitives): a generally
+    contracted basis through the whole path -- decontraction, splitting into <= 3-primitive shells, sorting, padding, the tiled
+    kernels, the epilogue -- against the CPU oracle on the SEGMENTED spelling of the same functions (another shell table)."""
+    from conftest import GENERAL_BASIS, SEGMENTED_BASIS
+    from joltqc_amd.constants import tile_width
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import jk as jkmod
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import dense
+    m1 = mole.Mole(atom=H2O, basis=GENERAL_BASIS, cart=cart)
+    m2 = mole.Mole(atom=H2O, basis=SEGMENTED_BASIS, cart=cart)
+    np.random.seed(9)
+    dm = np.random.rand(3, m1.nao, m1.nao)
+    dm[0] = dm[0] + dm[0].T
+    get_jk = jkmod.generate_jk_kernel(BasisLayout.from_mol(m1, alignment=tile_width), cutoff_fp64=1e-13, cutoff_fp32=1e-13)
+    vj, vk = get_jk(m1, dm, hermi=0)
+    rj, rk = dense.get_jk(BasisLayout.from_mol(m2), dm, hermi=0)
+    scale = max(np.abs(rj).max(), np.abs(rk).max())
+    assert np.abs(_np(vj) - rj).max() < 1e-11 * scale and np.abs(_np(vk) - rk).max() < 1e-11 * scale
+
+
+def test_shell_block_max_against_numpy():
+    """A5, reference backend/tests/test_linalg_helper.py::test_max_block_pooling: max |D| per shell block over all density
+    matrices, irregular shell widths incl. zero-width (padding) shells, float32 out."""
+    import torch
+    from joltqc_amd.backend import lib as L
+    dev = L.require_gpu()
+    rng = np.random.default_rng(42)
+    loc = np.array([0, 1, 1, 4, 10, 10, 25, 31, 40], dtype=np.int32)         # widths 1, 0, 3, 6, 0, 15, 6, 9
+    nb, nao = len(loc) - 1, int(loc[-1])
+    for n_dm in (1, 3):
+        d = rng.normal(size=(n_dm, nao, nao)) * rng.choice([1e-8, 1.0, 1e3], size=(n_dm, nao, nao))
+        ref = np.zeros((nb, nb), dtype=np.float32)
+        for i in range(nb):
+            for j in range(nb):
+                blk = np.abs(d[:, loc[i]:loc[i + 1], loc[j]:loc[j + 1]])
+                ref[i, j] = blk.max() if blk.size else 0.0
+        dt = torch.from_numpy(d).to(dev).contiguous()
+        out = torch.full((nb, nb), -1.0, dtype=torch.float32, device=dev)
+        L.check(L.lib().jqc_shell_block_max(dt.data_ptr(), n_dm, nao, torch.from_numpy(loc).to(dev).data_ptr(), nb, out.data_ptr(),
+                                          L.stream_ptr()))
+        got = out.cpu().numpy()
+        assert np.allclose(got, ref, rtol=1e-6, atol=0), np.abs(got - ref).max()
