@@ -106,3 +106,52 @@ def test_general_contractions_are_decontracted_and_split(cart):
     d = d + d.T
     (j1, k1), (j2, k2) = dense.get_jk(l1, d, 1), dense.get_jk(l2, d, 1)
     assert np.abs(j1 - j2).max() < 1e-12 * np.abs(j1).max() and np.abs(k1 - k2).max() < 1e-12 * np.abs(k1).max()
+
+
+def test_no_splitting_needed_and_alignments():
+    """Reference test_split_basis_no_splitting_needed / test_different_alignments / test_padding_logic: a basis whose
+    contractions have at most NPRIM_MAX primitives is only sorted; every alignment pads each (l, nprim) group to a multiple of
+    itself with zero-width copies and leaves the AO count alone."""
+    basis = {"O": [[0, [8.0, 0.3], [1.5, 0.5], [0.4, 0.4]], [0, [0.2, 1.0]], [1, [1.2, 0.6], [0.3, 0.5]], [2, [0.8, 1.0]]],
+             "H": [[0, [3.0, 0.2], [0.5, 0.8]], [1, [0.7, 1.0]]]}
+    m = mole.Mole(atom=H2O, basis=basis)
+    shells, parent = split_basis(m)
+    assert len(shells) == np.asarray(m._bas).shape[0] and np.array_equal(parent, np.arange(len(shells)))
+    base = BasisLayout.from_mol(m, alignment=1)
+    assert not base.pad_id.any() and base.nbasis == len(shells)
+    for align in (2, 4, 8):
+        lay = BasisLayout.from_mol(m, alignment=align)
+        assert np.all(np.diff(lay.group_offset) % align == 0) and lay.nao == base.nao
+        assert (~lay.pad_id).sum() == base.nbasis and np.all(np.diff(lay.ao_loc)[lay.pad_id] == 0)
+        # a pad is a copy of a real shell of its own group (finite exponents, harmless in every kernel)
+        for g in range(lay.ngroups):
+            sl = slice(lay.group_offset[g], lay.group_offset[g + 1])
+            real = lay.packed[sl][~lay.pad_id[sl]]
+            for row in lay.packed[sl][lay.pad_id[sl]]:
+                assert any(np.array_equal(row[[0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11]], r[[0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11]]) for r in real)
+
+
+@pytest.mark.parametrize("cart", [False, True])
+def test_maps_and_transformation_consistency(cart):
+    """Reference test_basis_mapping_consistency / test_to_decontracted_map_consistency / test_matrix_transformation_stability:
+    every internal shell points at a decontracted parent of the same angular momentum and atom; the overlap of the internal
+    (split, Cartesian) functions folded back with T is the overlap of the molecule's normalised AOs.  (Stacked matrices through
+    the device transforms: tests/test_jk_gpu.py::test_dm_transforms_of_stacked_matrices.)"""
+    from conftest import GENERAL_BASIS
+    from oracle import md_eri
+    m = mole.Mole(atom=H2O, basis=GENERAL_BASIS, cart=cart)
+    lay = BasisLayout.from_mol(m, alignment=4)
+    shells, parent = split_basis(m)
+    assert len(parent) == len(shells) and parent.max() + 1 == int(np.asarray(m._bas)[:, 3].sum())
+    for n in range(lay.nbasis):
+        s = shells[lay.to_split_map[n]]
+        assert s.l == lay.angs[n] and s.atom == lay.atom_of[n] and len(s.exps) == lay.nprims[n]
+    # overlap of the internal (split, Cartesian) functions folded back with T: symmetric, positive definite, and -- for a
+    # spherical basis, whose AOs PySCF normalises to one -- with a unit diagonal (checks T, the s/p factors and the split
+    # coefficients together; libcint's Cartesian d..g components are not all unit-normalised)
+    T = lay.transform_matrix()
+    s_int = md_eri.int1e(lay.packed, lay.ao_loc, m.atom_coords(), m.atom_charges())[0]
+    s_mol = T.T @ s_int @ T
+    assert np.abs(s_mol - s_mol.T).max() < 1e-13 and np.linalg.eigvalsh(s_mol).min() > 1e-4
+    if not cart:
+        assert np.abs(np.diag(s_mol) - 1.0).max() < 1e-10

@@ -376,3 +376,24 @@ def test_shell_block_max_against_numpy():
                                           L.stream_ptr()))
         got = out.cpu().numpy()
         assert np.allclose(got, ref, rtol=1e-6, atol=0), np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("cart", [False, True])
+def test_dm_transforms_of_stacked_matrices(cart):
+    """A4, reference test_basis_layout.py::test_3d_array_handling / test_dm_from_mol_dimensions / test_dm_to_mol_dimensions:
+    ``dm_from_mol`` / ``dm_to_mol`` on the device, single and stacked matrices, against T D T^T / T^T V T in NumPy."""
+    from conftest import GENERAL_BASIS
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    m = mole.Mole(atom=H2O, basis=GENERAL_BASIS, cart=cart)
+    lay = BasisLayout.from_mol(m, alignment=4)
+    T = lay.transform_matrix()
+    rng = np.random.default_rng(2)
+    d3 = rng.random((3, m.nao, m.nao))
+    out3 = _np(lay.dm_from_mol(d3))
+    assert out3.shape == (3, lay.nao, lay.nao) and np.abs(out3 - np.einsum("pi,nij,qj->npq", T, d3, T)).max() < 1e-12
+    assert np.abs(_np(lay.dm_from_mol(d3[1])) - out3[1]).max() < 1e-13
+    v3 = rng.random((3, lay.nao, lay.nao))
+    back3 = _np(lay.dm_to_mol(v3))
+    assert back3.shape == (3, m.nao, m.nao) and np.abs(back3 - np.einsum("pi,npq,qj->nij", T, v3, T)).max() < 1e-12
+    assert np.abs(_np(lay.dm_to_mol(v3[2])) - back3[2]).max() < 1e-13
