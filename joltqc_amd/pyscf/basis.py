@@ -19,6 +19,8 @@ MI355X-first differences (results are unchanged, see tests/test_basis_layout.py)
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
+import os
+
 import numpy as np
 
 from ..constants import BASIS_STRIDE, LMAX, NPRIM_MAX, SLOT_ANG, SLOT_NPRIM
@@ -63,6 +65,86 @@ def split_basis(mol):
     return shells, np.array([s.parent for s in shells], dtype=np.int32)
 
 
+# How the shells of an (l, nprim) group are ordered, i.e. which shells share a tile (a run of `alignment` shells).  A listed (bra
+# tile pair, ket tile pair) keeps the more of its candidate quartets the more alike the Schwarz bounds of a tile pair's shell
+# pairs are, i.e. the more COMPACT the tiles: measured on 112 atoms / def2-TZVPP (profiles/r02_tile_clustering_*), J+K step
+#   "morton"   shells along a Morton curve (rounds 1-2 until here)                                   6 218 ms
+#   "cluster"  tile = next free shell on the curve + its nearest free neighbours                     5 526 ms
+#   "cluster2" the same with seeds taken from the outside in (free shell farthest from the centroid)   5 356 ms   <- default
+#   "cluster3" cluster2 + pairwise-swap refinement of the tiles (2.7 s of host time)                  5 320 ms
+#   "cluster_exp" classes of similar exponents first, clusters inside (larger tiles)                  5 640-5 943 ms
+# Results do not depend on the order (tests/test_basis_layout.py, every GPU parity test).
+SPATIAL_MODE = os.environ.get("JQC_SPATIAL_SORT", "cluster2")
+EXP_CLASS = float(os.environ.get("JQC_EXP_CLASS", "2.5"))
+
+
+def _cluster_tiles(idxs, coords, width):
+    free = np.ones(len(idxs), dtype=bool)
+    out = []
+    if SPATIAL_MODE.startswith(("cluster2", "cluster3")):                 # seeds from the outside in: the free shell farthest from the centroid of the rest
+        while free.any():
+            cand = np.nonzero(free)[0]
+            c0 = coords[cand].mean(0)
+            seed = int(cand[np.argmax(((coords[cand] - c0) ** 2).sum(1))])
+            free[seed] = False
+            cand = np.nonzero(free)[0]
+            take = [seed]
+            if cand.size:
+                d = ((coords[cand] - coords[seed]) ** 2).sum(1)
+                take += [int(c) for c in cand[np.argsort(d, kind="stable")[:width - 1]]]
+            free[take] = False
+            out += [idxs[t] for t in take]
+        if SPATIAL_MODE.startswith("cluster3"):
+            out = _refine_tiles(out, {i: c for i, c in zip(idxs, coords)}, width)
+        return out
+    for seed in range(len(idxs)):
+        if not free[seed]:
+            continue
+        free[seed] = False
+        cand = np.nonzero(free)[0]
+        take = [seed]
+        if cand.size:
+            d = ((coords[cand] - coords[seed]) ** 2).sum(1)
+            take += [int(c) for c in cand[np.argsort(d, kind="stable")[:width - 1]]]
+        free[take] = False
+        out += [idxs[t] for t in take]
+    return out
+
+
+def _refine_tiles(order, coord_of, width, sweeps=6, near=6):
+    """Local search on a tiling (runs of ``width`` entries of ``order``): swap two shells of neighbouring tiles whenever that
+    lowers the summed squared distance of the shells to their tile centroids."""
+    n = len(order) // width
+    if n < 2:
+        return order
+    tiles = [list(order[t * width:(t + 1) * width]) for t in range(n)]
+    rest = list(order[n * width:])
+    xyz = lambda t: np.array([coord_of[i] for i in t])
+    ssd = lambda t: float(((xyz(t) - xyz(t).mean(0)) ** 2).sum())
+    for _ in range(sweeps):
+        cen = np.array([xyz(t).mean(0) for t in tiles])
+        changed = False
+        for a in range(n):
+            nb = np.argsort(((cen - cen[a]) ** 2).sum(1))[1:near + 1]
+            for b in nb:
+                base = ssd(tiles[a]) + ssd(tiles[b])
+                best, arg = base, None
+                for ia in range(width):
+                    for ib in range(width):
+                        ta, tb = list(tiles[a]), list(tiles[b])
+                        ta[ia], tb[ib] = tb[ib], ta[ia]
+                        v = ssd(ta) + ssd(tb)
+                        if v < best - 1e-12:
+                            best, arg = v, (ia, ib)
+                if arg is not None:
+                    ia, ib = arg
+                    tiles[a][ia], tiles[b][ib] = tiles[b][ib], tiles[a][ia]
+                    changed = True
+        if not changed:
+            break
+    return [i for t in tiles for i in t] + rest
+
+
 def sort_group_basis(shells, alignment=1, spatial_sort=True):
     """Group split shells by (l, nprim), l ascending then nprim descending, pad every group to a
     multiple of ``alignment`` with zero-width duplicates of its first shell
@@ -90,6 +172,19 @@ def sort_group_basis(shells, alignment=1, spatial_sort=True):
                 return (code, i)
             idxs = sorted(idxs, key=morton)
         align = alignment(k[0]) if callable(alignment) else int(alignment)
+        if spatial_sort and SPATIAL_MODE.startswith("cluster") and align > 1 and len(idxs) > align:
+            if SPATIAL_MODE.endswith("_exp"):
+                # shells of similar extent together: classes of the most diffuse exponent (factor EXP_CLASS apart), most diffuse
+                # class first, spatial clusters inside each class
+                cls = {}
+                for i in idxs:
+                    cls.setdefault(int(np.floor(np.log(float(np.min(shells[i].exps))) / np.log(EXP_CLASS))), []).append(i)
+                idxs = []
+                for c in sorted(cls):
+                    sub = cls[c]
+                    idxs += _cluster_tiles(sub, np.array([shells[i].coord for i in sub]), align) if len(sub) > align else sub
+            else:
+                idxs = _cluster_tiles(idxs, np.array([shells[i].coord for i in idxs]), align)
         npad = (-len(idxs)) % align
         order += idxs + [idxs[0]] * npad
         pad += [False] * len(idxs) + [True] * npad
