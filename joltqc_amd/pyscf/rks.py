@@ -16,6 +16,7 @@ AO pairs above ``cutoff_fp64`` form a corner of the block's pair matrix that goe
 ``cutoff_fp32`` through the FP32 MFMA (twice the rate), the rest is skipped.
 """
 import math
+import os
 
 import numpy as np
 
@@ -462,7 +463,8 @@ GROUP_BOX_SIZE = 3.0      # reference rks.py:56
 
 def arg_group_grids(coords, box_size=GROUP_BOX_SIZE):
     """Order that groups grid points by cubic boxes so that 256-point blocks are spatially compact
-    (reference arg_group_grids, rks.py:71-97)."""
+    (reference arg_group_grids, rks.py:71-97).  (Boxes along a Morton curve instead of x-major rows were tried: sum of squared
+    AO counts per block +3 %, rho 9.0 -> 10.2 ms on the 112-atom Becke grid -- the row order stays.)"""
     c = np.asarray(coords)
     lo = c.min(axis=0)
     box = np.floor((c - lo) / box_size).astype(np.int64)
