@@ -461,38 +461,12 @@ def generate_nr_nlc_vxc(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
 GROUP_BOX_SIZE = 3.0      # reference rks.py:56
 
 
-GRID_ORDER = os.environ.get("JQC_GRID_ORDER", "rows")      # "rows": the reference's box order; "kdtree": balanced bisection
-
-
-def _kdtree_order(c, leaf=NG):
-    """Recursive bisection along the longest axis into leaves of exactly ``leaf`` points (the last one takes the remainder):
-    every 256-point block is a compact box whatever the local point density."""
-    out = []
-    stack = [np.arange(len(c))]
-    while stack:
-        idx = stack.pop()
-        n = len(idx)
-        if n <= leaf:
-            out.append(idx)
-            continue
-        nleft = max(leaf, int(round(n / 2 / leaf)) * leaf)
-        if nleft >= n:
-            nleft = n - (n % leaf or leaf)
-        p = c[idx]
-        ax = int(np.argmax(p.max(0) - p.min(0)))
-        part = np.argpartition(p[:, ax], nleft - 1)
-        stack.append(idx[part[nleft:]])              # (popped after the left half: leaves come out in tree order)
-        stack.append(idx[part[:nleft]])
-    return np.concatenate(out)
-
-
 def arg_group_grids(coords, box_size=GROUP_BOX_SIZE):
     """Order that groups grid points by cubic boxes so that 256-point blocks are spatially compact
-    (reference arg_group_grids, rks.py:71-97).  (Boxes along a Morton curve instead of x-major rows were tried: sum of squared
-    AO counts per block +3 %, rho 9.0 -> 10.2 ms on the 112-atom Becke grid -- the row order stays.)"""
+    (reference arg_group_grids, rks.py:71-97).  (Tried on the 112-atom Becke grid and rejected: boxes along a Morton curve -- sum of
+    squared AO counts per block +3 %, rho 9.0 -> 10.2 ms; balanced k-d bisection into 256-point leaves -- +5.7 %, 9.2 -> 10.3 ms.
+    Atom-centred shells of points are already compact in the row order.)"""
     c = np.asarray(coords)
-    if GRID_ORDER == "kdtree":
-        return _kdtree_order(c)
     lo = c.min(axis=0)
     box = np.floor((c - lo) / box_size).astype(np.int64)
     nb = box.max(axis=0) + 1
