@@ -149,8 +149,8 @@ def sort_group_basis(shells, alignment=1, spatial_sort=True):
     """Group split shells by (l, nprim), l ascending then nprim descending, pad every group to a
     multiple of ``alignment`` with zero-width duplicates of its first shell
     (reference ``basis.py:483-675``).  Within a group the reference keeps molecule order; this build
-    can additionally order shells along a Morton curve so that neighbouring shells are close in
-    space (denser screening strips); results do not depend on the order."""
+    arranges the shells so that every tile (run of ``alignment`` shells) is spatially compact
+    (``SPATIAL_MODE`` above); results do not depend on the order."""
     groups: Dict[Tuple[int, int], list] = {}
     for idx, s in enumerate(shells):
         groups.setdefault((s.l, len(s.exps)), []).append(idx)
