@@ -67,15 +67,18 @@ def split_basis(mol):
 
 # How the shells of an (l, nprim) group are ordered, i.e. which shells share a tile (a run of `alignment` shells).  A listed (bra
 # tile pair, ket tile pair) keeps the more of its candidate quartets the more alike the Schwarz bounds of a tile pair's shell
-# pairs are, i.e. the more COMPACT the tiles: measured on 112 atoms / def2-TZVPP (profiles/r02_tile_clustering_*), J+K step
-#   "morton"   shells along a Morton curve (rounds 1-2 until here)                                   6 218 ms
-#   "cluster"  tile = next free shell on the curve + its nearest free neighbours                     5 526 ms
-#   "cluster2" the same with seeds taken from the outside in (free shell farthest from the centroid)   5 356 ms   <- default
-#   "cluster3" cluster2 + pairwise-swap refinement of the tiles (2.7 s of host time)                  5 320 ms
-#   "cluster_exp" classes of similar exponents first, clusters inside (larger tiles)                  5 640-5 943 ms
+# pairs are, i.e. the more alike the shells of a tile are in POSITION and in EXTENT.  Tiles are clusters in the four coordinates
+# (x, y, z, EXP_WEIGHT * ln(most diffuse exponent)).  Measured on 112 atoms / def2-TZVPP (profiles/r02_tile_clustering_*), J+K step:
+#   "morton"   shells along a Morton curve (until round 2)                                              6 218 ms
+#   "cluster"  tile = next free shell on the curve + its nearest free neighbours (position only)        5 526 ms
+#   "cluster2" the same with seeds taken from the outside in (free shell farthest from the centroid)   5 356 ms
+#   "cluster2" + exponent coordinate, EXP_WEIGHT = 2 / 4 / 5 / 6 / 10 Bohr per e-fold   5 210 / 5 012 / 4 962 / 4 982 / 5 030 ms
+#   "cluster3" cluster2 + pairwise-swap refinement of the tiles, EXP_WEIGHT = 5                        4 917 ms   <- default
+#   "cluster_exp" hard classes of similar exponents first, clusters inside (larger tiles)               5 640-5 943 ms
 # Results do not depend on the order (tests/test_basis_layout.py, every GPU parity test).
-SPATIAL_MODE = os.environ.get("JQC_SPATIAL_SORT", "cluster2")
+SPATIAL_MODE = os.environ.get("JQC_SPATIAL_SORT", "cluster3")
 EXP_CLASS = float(os.environ.get("JQC_EXP_CLASS", "2.5"))
+EXP_WEIGHT = float(os.environ.get("JQC_EXP_WEIGHT", "5"))
 
 
 def _cluster_tiles(idxs, coords, width):
@@ -113,36 +116,32 @@ def _cluster_tiles(idxs, coords, width):
 
 def _refine_tiles(order, coord_of, width, sweeps=6, near=6):
     """Local search on a tiling (runs of ``width`` entries of ``order``): swap two shells of neighbouring tiles whenever that
-    lowers the summed squared distance of the shells to their tile centroids."""
+    lowers the summed squared distance of the shells to their tile centroids.  With sum_i |p_i - c|^2 = sum |p_i|^2 - |S|^2 / w
+    (S = sum of the tile's points) a swap a_i <-> b_j changes the total by (|S_A|^2 + |S_B|^2 - |S_A - d|^2 - |S_B + d|^2) / w,
+    d = a_i - b_j: all w x w candidate swaps of a tile pair at once."""
     n = len(order) // width
     if n < 2:
         return order
-    tiles = [list(order[t * width:(t + 1) * width]) for t in range(n)]
+    P = np.array([coord_of[i] for i in order[:n * width]]).reshape(n, width, -1)
+    ids = np.array(order[:n * width]).reshape(n, width)
     rest = list(order[n * width:])
-    xyz = lambda t: np.array([coord_of[i] for i in t])
-    ssd = lambda t: float(((xyz(t) - xyz(t).mean(0)) ** 2).sum())
     for _ in range(sweeps):
-        cen = np.array([xyz(t).mean(0) for t in tiles])
+        cen = P.mean(1)
         changed = False
         for a in range(n):
-            nb = np.argsort(((cen - cen[a]) ** 2).sum(1))[1:near + 1]
-            for b in nb:
-                base = ssd(tiles[a]) + ssd(tiles[b])
-                best, arg = base, None
-                for ia in range(width):
-                    for ib in range(width):
-                        ta, tb = list(tiles[a]), list(tiles[b])
-                        ta[ia], tb[ib] = tb[ib], ta[ia]
-                        v = ssd(ta) + ssd(tb)
-                        if v < best - 1e-12:
-                            best, arg = v, (ia, ib)
-                if arg is not None:
-                    ia, ib = arg
-                    tiles[a][ia], tiles[b][ib] = tiles[b][ib], tiles[a][ia]
+            for b in np.argsort(((cen - cen[a]) ** 2).sum(1))[1:near + 1]:
+                sa, sb = P[a].sum(0), P[b].sum(0)
+                d = P[a][:, None, :] - P[b][None, :, :]                       # [ia, ib, dim]
+                gain = ((sa ** 2).sum() + (sb ** 2).sum() - ((sa - d) ** 2).sum(2) - ((sb + d) ** 2).sum(2)) / width
+                k = int(np.argmin(gain))
+                if gain.flat[k] < -1e-12:
+                    ia, ib = divmod(k, width)
+                    P[a, ia], P[b, ib] = P[b, ib].copy(), P[a, ia].copy()
+                    ids[a, ia], ids[b, ib] = ids[b, ib], ids[a, ia]
                     changed = True
         if not changed:
             break
-    return [i for t in tiles for i in t] + rest
+    return [int(i) for i in ids.reshape(-1)] + rest
 
 
 def sort_group_basis(shells, alignment=1, spatial_sort=True):
@@ -184,7 +183,10 @@ def sort_group_basis(shells, alignment=1, spatial_sort=True):
                     sub = cls[c]
                     idxs += _cluster_tiles(sub, np.array([shells[i].coord for i in sub]), align) if len(sub) > align else sub
             else:
-                idxs = _cluster_tiles(idxs, np.array([shells[i].coord for i in idxs]), align)
+                xyz = np.array([shells[i].coord for i in idxs])
+                if EXP_WEIGHT > 0:      # fourth coordinate: log of the most diffuse exponent (Bohr per e-fold), see the table above
+                    xyz = np.hstack([xyz, EXP_WEIGHT * np.log([[float(np.min(shells[i].exps))] for i in idxs])])
+                idxs = _cluster_tiles(idxs, xyz, align)
         npad = (-len(idxs)) % align
         order += idxs + [idxs[0]] * npad
         pad += [False] * len(idxs) + [True] * npad
