@@ -155,3 +155,45 @@ def test_maps_and_transformation_consistency(cart):
     assert np.abs(s_mol - s_mol.T).max() < 1e-13 and np.linalg.eigvalsh(s_mol).min() > 1e-4
     if not cart:
         assert np.abs(np.diag(s_mol) - 1.0).max() < 1e-10
+
+
+def test_tiles_are_compact_clusters_and_the_order_is_a_deterministic_permutation():
+    """Tile composition (pyscf/basis.py:_cluster_tiles / _refine_tiles): whatever the mode, the layout is a permutation of the
+    split shells grouped by (l, nprim); the default clusters have a markedly smaller radius than runs cut from a Morton curve
+    (that is what raises the survival of the quartet screening); two builds give the same order."""
+    import joltqc_amd.pyscf.basis as B
+    from joltqc_amd.constants import tile_width
+    mol = mole.Mole(atom=benzene_atoms() + [("C", (6.0 + 1.4 * k, 0.3 * k, 0.2 * k * k)) for k in range(6)], basis="def2-tzvpp")
+
+    def radii(lay):
+        out = {}
+        for g in range(lay.ngroups):
+            w = tile_width(int(lay.group_key[g, 0]))
+            c = lay.packed[lay.group_offset[g]:lay.group_offset[g + 1], :3]
+            n = len(c) // w
+            if w > 1 and n > 1:
+                t = c[:n * w].reshape(n, w, 3)
+                out[tuple(lay.group_key[g])] = float(np.sqrt(((t - t.mean(1, keepdims=True)) ** 2).sum(2)).max(1).mean())
+        return out
+
+    saved = B.SPATIAL_MODE, B.EXP_WEIGHT
+    try:
+        lays = {}
+        for mode, wgt in (("morton", 0.0), ("cluster2", 0.0), (saved[0], saved[1])):
+            B.SPATIAL_MODE, B.EXP_WEIGHT = mode, wgt
+            lay = BasisLayout.from_mol(mol, alignment=tile_width)
+            real = lay.to_split_map[~lay.pad_id]
+            assert sorted(real.tolist()) == list(range(len(real)))
+            for g in range(lay.ngroups):
+                sl = slice(lay.group_offset[g], lay.group_offset[g + 1])
+                assert np.all(lay.angs[sl] == lay.group_key[g, 0]) and np.all(lay.nprims[sl] == lay.group_key[g, 1])
+            lays[mode] = lay
+        again = BasisLayout.from_mol(mol, alignment=tile_width)
+        assert np.array_equal(again.to_split_map, lays[saved[0]].to_split_map)
+        r_m, r_c = radii(lays["morton"]), radii(lays["cluster2"])
+        # (the 8-wide s tiles of so small a molecule span most of it either way: the p and d groups show the effect)
+        pd = [k for k in r_m if k[0] in (1, 2) and k[1] == 1]
+        assert pd and all(r_c[k] < 0.8 * r_m[k] for k in pd), (r_m, r_c)
+        assert sum(r_c.values()) < sum(r_m.values())
+    finally:
+        B.SPATIAL_MODE, B.EXP_WEIGHT = saved
