@@ -727,6 +727,9 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
     if (!g_rys64) return fail(-1, "Rys tables not uploaded (jqc_set_rys_tables)");
     if (nbas > 46340) return fail(-1, "nbas = %d: the kernels index nbas x nbas tables with 32-bit integers (limit 46340)", nbas);
     if (ntasks <= 0 || nblocks <= 0) return 0;
+    // the AQL dispatch packet holds the grid size in WORK-ITEMS as 32 bits: a larger grid is truncated without an error
+    if ((unsigned long long)nblocks * 512ull >= (1ull << 32))
+        return fail(-1, "%d workgroups exceed the 32-bit work-item count of one launch: use longer ket chunks", nblocks);
     const int n = k.nroots;
     float omega_f = (float)omega;
     const void* cheb = k.fp32 ? (const void*)rys_cheb32(n) : (const void*)rys_cheb64(n);

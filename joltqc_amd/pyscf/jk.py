@@ -347,6 +347,10 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
         # the class still fills the chip (>= TARGET_WGS workgroups) the chunks grow up to KCHUNK_MAX
         nblk1 = sum(r[1] * r[3] for r in rows)
         kchunk = int(min(KCHUNK_MAX, max(1, nblk1 // TARGET_WGS)))
+        # hard limit of a launch: the dispatch packet counts WORK-ITEMS in 32 bits, i.e. at most 2^24 - 1 workgroups of 256 --
+        # a larger grid is silently truncated (found with KCHUNK_MAX = 1 on the 425-atom molecule: J off by 70 %).  Longer ket
+        # chunks keep every class under it whatever the molecule size and the knobs.
+        kchunk = max(kchunk, -(-nblk1 // MAX_WGS_PER_LAUNCH))
         # small launches (few tile pairs, e.g. the f classes of a small molecule): deal the candidates of every tile
         # pair to nsplit workgroups so that the class still spreads over the chip
         nq = 1
@@ -361,7 +365,8 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
             nchunk = -(-nkl // kchunk)
             tab[n] = (ij0, nij, kl0, nkl, nchunk, blk, 0, kchunk | (nsplit << 16))
             blk += nij * nchunk * nsplit
-            assert blk < 2 ** 31
+        if blk * 512 >= 2 ** 32:                 # (512: the widest workgroup of the tiled kernels)
+            raise RuntimeError(f"class {ang}: {blk} workgroups exceed the 32-bit work-item count of one launch")
         # coarse index: task row of every 256th workgroup (the kernel probes forward from there)
         starts = tab[:, 5].astype(np.int64)
         index = (np.searchsorted(starts, np.arange(0, blk + 256, 256), side="right") - 1).astype(np.int32)
@@ -406,6 +411,7 @@ KCHUNK_MAX = int(__import__('os').environ.get('JQC_KCHUNK_MAX', '16'))
 SPLIT_BELOW_WGS = int(__import__('os').environ.get('JQC_SPLIT_BELOW', '1024'))
 NSPLIT_MAX = int(__import__('os').environ.get('JQC_NSPLIT_MAX', '8'))
 TARGET_WGS = int(__import__('os').environ.get('JQC_TARGET_WGS', '4096'))
+MAX_WGS_PER_LAUNCH = 4_000_000       # < 2^32 / 512 work-items per launch (see build_tile_plan)
 
 
 def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard=None):

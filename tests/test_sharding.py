@@ -105,3 +105,37 @@ def test_two_rank_allreduce_equals_single_rank():
     vj, vk = O.jk_raw(lay.packed, ret["dm"], dense.canonical_quartets(lay))
     assert np.abs(ret["fock"][0] - vj[0]).max() < 1e-11
     assert np.abs(ret["fock"][1] - vk[0]).max() < 1e-11
+
+
+def test_launches_stay_below_the_work_item_limit(monkeypatch):
+    """A launch of more than 2^24 - 1 workgroups of 256 is silently truncated by the hardware queue (32-bit work-item count):
+    build_tile_plan lengthens the ket chunks until every class fits, whatever KCHUNK_MAX says (here with a toy limit); the
+    task rectangles (bra range x ket range) -- i.e. the quartets covered -- do not change, only how many workgroups share them."""
+    import math
+    from conftest import benzene_atoms
+    from joltqc_amd.constants import tile_width
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import jk as jkmod
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import jk as O
+    mol = mole.Mole(atom=benzene_atoms(), basis="def2-svp")
+    lay = BasisLayout.from_mol(mol, alignment=tile_width)
+    q = np.log(O.schwarz(lay.packed) + 1e-300).astype(np.float32)
+    q[lay.pad_id, :] = -100
+    q[:, lay.pad_id] = -100
+    tt = jkmod._TileTables(lay, 0.0, q_host=q)
+    log_cut, log_dm = math.log(1e-13), 2.0
+    monkeypatch.setattr(jkmod, "KCHUNK_MAX", 1)
+    monkeypatch.setattr(jkmod, "NSPLIT_MAX", 1)
+    free = jkmod.build_tile_plan(lay, tt, log_cut, log_dm, lambda a: True)
+    monkeypatch.setattr(jkmod, "MAX_WGS_PER_LAUNCH", 40)
+    capped = jkmod.build_tile_plan(lay, tt, log_cut, log_dm, lambda a: True)
+    assert max(p[1] for p in free.values()) > 400                     # the toy limit bites
+    for ang, (tab, nblk, _, index) in capped.items():
+        f = free[ang][0]
+        assert np.array_equal(tab[:, :4], f[:, :4])                  # same rectangles
+        nbra = int(tab[:, 1].sum())
+        assert nblk <= 40 + nbra, (ang, nblk)                        # ceil() per task row: at most one extra chunk per bra pair
+        kch = tab[:, 7] & 0xffff
+        assert (kch == kch[0]).all() and kch[0] >= math.ceil(int((f[:, 1] * f[:, 3]).sum()) / 40)
+        assert np.array_equal(tab[:, 4], -(-tab[:, 3] // kch)) and index[-1] == tab.shape[0] - 1
