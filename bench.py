@@ -334,7 +334,7 @@ def main():
         if world == 1:
             # the dense density above disables density screening (as the reference's ones-D benchmark does); the same
             # build with a density of SCF-like decay, D = C C^T / n_occ, for orientation (not `value`)
-            get_jk.set_streams(jkmod.N_STREAMS)
+            get_jk.set_streams(None)
             get_jk.set_probe(None)
             nocc = max(mol.nelectron // 2, 1)
             np.random.seed(9)

@@ -30,6 +30,9 @@ PAIR_CUTOFF = 1e-13          # reference jk.py:48
 QUEUE_DEPTH = 1 << 26        # quartets per chunk (8 B each -> 512 MiB); reference uses 2^28 (jk_tasks.py:30)
 STRIPS_PER_LIST = 64         # host-side trimming granularity of the sorted pair lists
 N_STREAMS = int(__import__('os').environ.get('JQC_STREAMS', '8'))                # class kernels are independent (atomic accumulation): spread them over HIP streams
+N_STREAMS_BIG = 4            # calls whose class launches each fill the chip many times over: fewer kernels in flight (4 790 ms
+                             # against 4 900 ms on the 112-atom step; benzene-size calls are faster on 8-16: 9.9-10.0 against 10.2 ms)
+BIG_CALL_WGS = 1_000_000     # summed workgroups of a call from which N_STREAMS_BIG applies (unless JQC_STREAMS / set_streams say otherwise)
 
 
 def generate_get_j(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13):
@@ -432,7 +435,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
     tiled_layout = all((layout.group_offset[g + 1] - layout.group_offset[g]) % tile_width(int(layout.group_key[g, 0])) == 0
                        for g in range(layout.ngroups))
     state = {"pairs": {}, "tiles": {}, "queue": None, "stats": {}, "probe": None, "plan_cache": {}, "streams": None,
-             "nstreams": N_STREAMS}
+             "nstreams": N_STREAMS, "auto_streams": "JQC_STREAMS" not in __import__('os').environ}
 
     def get_jk(mol_ref=None, dm=None, hermi=0, vhfopt=None, with_j=True, with_k=True, omega=None, verbose=None,
                _classes=None):
@@ -592,8 +595,11 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                 counts_buf = torch.zeros(32 + 2 * entry["nrows"], dtype=torch.int64, device=dev)
                 tile_counts = counts_buf[32:].view(2, entry["nrows"])
                 state["stats"]["stamps"] = counts_buf[:32]
-                if state["streams"] is None or len(state["streams"]) != state["nstreams"]:
-                    state["streams"] = [torch.cuda.Stream(device=dev) for _ in range(state["nstreams"])]
+                nst = state["nstreams"]
+                if state["auto_streams"] and sum(int(tplans[a][1]) for a in order) > BIG_CALL_WGS:
+                    nst = min(nst, N_STREAMS_BIG)
+                if state["streams"] is None or len(state["streams"]) != nst:
+                    state["streams"] = [torch.cuda.Stream(device=dev) for _ in range(nst)]
                 side = state["streams"]
                 if mixed:
                     tt.pair_tab32()            # created on the current stream BEFORE the side streams fork from it
@@ -723,8 +729,13 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
         state["stats"]["probe_classes"] = []
 
     def set_streams(n):
-        """Number of HIP streams the class kernels are spread over (1 = serial launches)."""
+        """Number of HIP streams the class kernels are spread over (1 = serial launches; None = the default policy: N_STREAMS,
+        N_STREAMS_BIG for calls of more than BIG_CALL_WGS workgroups)."""
+        if n is None:                                # back to the default policy
+            state["nstreams"], state["auto_streams"] = N_STREAMS, "JQC_STREAMS" not in __import__('os').environ
+            return
         state["nstreams"] = max(1, int(n))
+        state["auto_streams"] = False
 
     get_jk.set_streams = set_streams
     get_jk.set_probe = set_probe
