@@ -10,8 +10,12 @@ Follows (file:line under /root/reference):
       V_ab = sum_g [w0 phi_a phi_b + (w.grad phi_a) phi_b + phi_a (w.grad phi_b) + 1/2 w4 grad phi_a.grad phi_b]
   * VV10 double sum and its pre/post algebra                    jqc/backend/dft/vv10.cu:29-118, jqc/backend/rks.py:398-715
 The dense formulas ARE the reference tests' oracle (they compare against ni.eval_ao + ni.eval_rho and
-ao.dot((w ao).T)); the AO values are pinned independently by tests/test_dft_oracle.py (analytic
-normalisation integrals and finite-difference gradients).
+ao.dot((w ao).T)).  PINNED (tests/test_dft_known_answers.py): an RKS SCF built from this module, oracle/xc.py and
+oracle/rks.py reproduces the energies the reference's own tests hold for H2O / def2-TZVPP
+(jqc/pyscf/tests/test_dft.py:75-86): "LDA,vwn5" -75.9046410402 to 1e-9 Eh, "PBE" -76.3800182418 to 6e-8 Eh (LDA and GGA
+branches: AO values, gradients, the V_xc conventions).  The AO values are also checked against analytic normalisation
+integrals and finite differences (tests/test_dft_oracle.py); the meta-GGA tau term and VV10 have no reference-held number
+a closed-form functional could reproduce (M06 / wB97M-V need libxc) and stay pinned by those checks only.
 """
 import numpy as np
 

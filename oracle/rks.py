@@ -1,0 +1,53 @@
+"""Oracle-side Kohn-Sham potential: the reference's nr_rks + get_veff restated on the CPU.  TEST INFRASTRUCTURE ONLY.
+
+Follows /root/reference/jqc/pyscf/rks.py:308-364 (nr_rks: rho -> eval_xc_eff -> nelec, excsum, vxcmat; without the
+incremental bookkeeping, which changes no number) and :184-262 (get_veff for a pure functional: vxc + vj, ecoul =
+1/2 tr(D J), exc from the quadrature) with the dense AO formulas of oracle/dft.py, the closed-form functionals of
+oracle/xc.py and the Rys J/K oracle.  AO values on the grid are cached (they depend on the geometry only).
+"""
+import numpy as np
+
+from . import dft, xc
+
+
+class Tagged(np.ndarray):
+    """ndarray with the attributes PySCF's tag_array attaches to a potential (ecoul, exc, vj, vk)."""
+
+
+def make_get_veff(layout, coords, weights, xc_code, get_j):
+    """``get_veff(mol, dm, ...)`` of an RKS object for the pure functional ``xc_code``; ``get_j(dm) -> J`` in the
+    molecule's AO basis."""
+    kind = xc.xc_type(xc_code)
+    ao = dft.eval_ao_mol(layout, coords, deriv=0 if kind == "LDA" else 1)       # [ncomp, nao, ngrids]
+    w = np.asarray(weights, dtype=np.float64)
+    stats = {}
+
+    def nr_rks(dm):
+        dm = np.asarray(dm, dtype=np.float64)
+        c0 = dm @ ao[0]
+        rho = np.empty((dft.NDIM[kind], ao.shape[2]))
+        rho[0] = np.einsum("ig,ig->g", ao[0], c0)
+        for x in range(1, rho.shape[0]):
+            rho[x] = 2.0 * np.einsum("ig,ig->g", ao[x], c0)                     # symmetric D (reference eval_rho.cu:300-383)
+        exc, vxc = xc.eval_xc_eff(xc_code, rho if kind != "LDA" else rho[0])
+        den = rho[0] * w
+        wv = vxc * w
+        if kind == "LDA":
+            vmat = ao[0] @ (ao[0] * wv[0]).T
+        else:
+            wv[0] *= 0.5                                                        # reference tests/test_rks.py:158-162
+            v = ao[0] @ np.einsum("nig,ng->ig", ao, wv).T
+            vmat = v + v.T
+        return float(den.sum()), float((den * exc).sum()), vmat
+
+    def get_veff(mol=None, dm=None, dm_last=None, vhf_last=None, hermi=1):
+        dm = np.asarray(dm, dtype=np.float64)
+        nelec, exc, vxc = nr_rks(dm)
+        vj = get_j(dm)
+        out = (vxc + vj).view(Tagged)
+        out.ecoul = 0.5 * float(np.einsum("ij,ji->", dm, vj))
+        out.exc, out.vj, out.vk = exc, vj, None
+        stats["nelec"] = nelec
+        return out
+    get_veff.stats = stats
+    return get_veff

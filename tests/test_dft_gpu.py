@@ -196,6 +196,30 @@ def test_rks_scf_through_apply_matches_cpu_oracle_scf():
     assert abs(e_default - e_cpu) < 1e-6, e_default - e_cpu
 
 
+@pytest.mark.parametrize("xc_code,e_ref", [("lda,vwn5", -75.9046410402), ("pbe", -76.3800182418)])
+def test_reference_dft_energies_through_apply(kats, xc_code, e_ref):
+    """The reference's own known answers for the grid path (jqc/pyscf/tests/test_dft.py:75-86: H2O / def2-TZVPP, tolerance
+    1e-5): RKS through ``apply()`` -- device J (pair backend), rho_fun / vxc_fun on the MFMA kernels with the default
+    precision windows, the closed-form functional standing in for libxc, Becke grid of gto/grids.py."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from joltqc_amd.gto.grids import Grids
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from standin_scf import RKS, ClosedFormNumInt
+    from oracle import dense
+    mol = mole.Mole(atom=kats["h2o_def2tzvpp"]["atom"], basis="def2-tzvpp")
+    S, T, V = dense.int1e_mol(BasisLayout.from_mol(mol), mol)
+    mf = jp.apply(RKS(mol, T + V, S, Grids(mol, 90, 24), xc=xc_code, numint=ClosedFormNumInt()))
+    e = mf.kernel()
+    assert mf.converged
+    assert abs(e - e_ref) < 1e-5, e - e_ref          # the reference's bar (default mixed-precision windows included)
+    cfg = jp.get_default_config()
+    cfg["dft"] = {"cutoff_fp32": 1e-13, "cutoff_fp64": 1e-13}
+    mf64 = jp.apply(RKS(mol, T + V, S, Grids(mol, 90, 24), xc=xc_code, numint=ClosedFormNumInt()), cfg)
+    e64 = mf64.kernel()
+    assert abs(e64 - e_ref) < 1e-6, e64 - e_ref      # all-FP64 grid path: the CPU oracle's bar (tests/test_dft_known_answers.py)
+
+
 def test_build_grids_through_apply_on_a_generated_becke_grid():
     """A17 (reference rks.py:100-177): apply() replaces ``grids.build``; on first use the object's own generator runs (here the
     Becke generator of joltqc_amd/gto/grids.py standing in for PySCF's), the result is sorted into 1-Bohr boxes and padded to a
