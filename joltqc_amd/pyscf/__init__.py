@@ -154,13 +154,7 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
                 and not hasattr(obj, "_jqc_original_nuc_grad_method"):
             original_ngm = obj.nuc_grad_method
             obj._jqc_original_nuc_grad_method = original_ngm
-
-            def nuc_grad_method(*a, **k):
-                g = original_ngm(*a, **k)
-                g.grad_elec = lambda mo_energy=None, mo_coeff=None, mo_occ=None, atmlst=None: \
-                    _grad.rhf_grad_elec(obj, obj._jqc_jk_energy_per_atom)
-                return g
-            obj.nuc_grad_method = nuc_grad_method
+            obj.nuc_grad_method = lambda *a, **k: _grad.patch_gradients(original_ngm(*a, **k))
 
     if config.get("int1e") and not getattr(obj.mol, "has_ecp", lambda: False)():
         from . import int1e as _int1e

@@ -109,14 +109,20 @@ def generate_jk_energy_per_atom(basis_layout, cutoff=1e-13, shard=None):
     return jk_energy_per_atom
 
 
-def rhf_grad_elec(mf, jk_energy_per_atom, dm=None, hyb=1.0):
+def rhf_grad_elec(mf, jk_energy_per_atom, dm=None, hyb=1.0, mo_energy=None, mo_coeff=None, mo_occ=None, mol=None, atmlst=None):
     """Electronic RHF gradient [natm, 3] of a converged mean-field object whose molecule offers PySCF's derivative one-electron
     integrals (``mol.intor('int1e_ipovlp')``, ``int1e_ipkin``, ``int1e_ipnuc``, ``int1e_iprinv`` with ``with_rinv_at_nucleus``):
-    the one-electron and overlap terms as in ``pyscf.grad.rhf.grad_elec``, the two-electron term from the device kernels."""
-    mol = mf.mol
-    dm0 = mf.make_rdm1() if dm is None else dm
-    dm0 = np.asarray(dm0.cpu() if hasattr(dm0, "cpu") else dm0)
-    mo_e, mo_c, occ = (np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in (mf.mo_energy, mf.mo_coeff, mf.mo_occ))
+    the one-electron and overlap terms as in ``pyscf.grad.rhf.grad_elec``, the two-electron term from the device kernels.
+    ``mo_energy / mo_coeff / mo_occ`` default to the object's own, ``mol`` to ``mf.mol``; ``atmlst`` selects rows."""
+    mol = mf.mol if mol is None else mol
+    mo_energy = mf.mo_energy if mo_energy is None else mo_energy
+    mo_coeff = mf.mo_coeff if mo_coeff is None else mo_coeff
+    mo_occ = mf.mo_occ if mo_occ is None else mo_occ
+    mo_e, mo_c, occ = (np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in (mo_energy, mo_coeff, mo_occ))
+    if dm is None:
+        dm0 = (mo_c[:, occ > 0] * occ[occ > 0]) @ mo_c[:, occ > 0].T
+    else:
+        dm0 = np.asarray(dm.cpu() if hasattr(dm, "cpu") else dm)
     dme0 = (mo_c[:, occ > 0] * (mo_e[occ > 0] * occ[occ > 0])) @ mo_c[:, occ > 0].T
     s1 = -mol.intor("int1e_ipovlp", comp=3)
     h1 = -(mol.intor("int1e_ipkin", comp=3) + mol.intor("int1e_ipnuc", comp=3))
@@ -131,4 +137,34 @@ def rhf_grad_elec(mf, jk_energy_per_atom, dm=None, hyb=1.0):
         hc = hc + hc.transpose(0, 2, 1)
         de[ia] = np.einsum("xij,ij->x", hc, dm0) - 2.0 * np.einsum("xij,ij->x", s1[:, p0:p1], dme0[p0:p1])
     ejk = jk_energy_per_atom(mol, dm0, j_factor=1.0, k_factor=hyb)
-    return de + np.asarray(ejk.cpu() if hasattr(ejk, "cpu") else ejk)
+    de = de + np.asarray(ejk.cpu() if hasattr(ejk, "cpu") else ejk)
+    return de if atmlst is None else de[list(atmlst)]
+
+
+def patch_gradients(g):
+    """Route ``grad_elec`` of a PySCF ``Gradients`` object (``mf.nuc_grad_method()``) through the device kernels.
+
+    The override lives on a SUBCLASS of the object's class, not in its ``__dict__``: PySCF's ``g.as_scanner()`` (geomeTRIC /
+    berny optimisers) copies ``g.__dict__`` into an instance of a class derived from ``g.__class__`` and replaces ``g.base``
+    by ``base.as_scanner()``, so an instance attribute bound to the old object would keep answering for the old geometry.
+    ``grad_elec`` therefore reads everything from ``self``: ``self.base`` (the mean field the scanner has just converged,
+    with the ``_jqc_jk_energy_per_atom`` closure its own ``apply`` / ``reset`` installed) and ``self.mol``.  Molecules
+    with ECPs keep PySCF's own ``grad_elec`` (the ECP gradient terms are not built here)."""
+    base_cls = g.__class__
+    if getattr(base_cls, "_jqc_patched", False):
+        return g
+
+    class JQCGradients(base_cls):
+        _jqc_patched = True
+
+        def grad_elec(self, mo_energy=None, mo_coeff=None, mo_occ=None, atmlst=None):
+            mf = self.base
+            fn = getattr(mf, "_jqc_jk_energy_per_atom", None)
+            mol = getattr(self, "mol", None) or mf.mol
+            if fn is None or getattr(mol, "has_ecp", lambda: False)():
+                return base_cls.grad_elec(self, mo_energy, mo_coeff, mo_occ, atmlst)
+            return rhf_grad_elec(mf, fn, mo_energy=mo_energy, mo_coeff=mo_coeff, mo_occ=mo_occ, mol=mol, atmlst=atmlst)
+
+    JQCGradients.__name__ = base_cls.__name__
+    g.__class__ = JQCGradients
+    return g

@@ -37,6 +37,9 @@ def lib():
                                           ctypes.c_double, dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int]
         L.jqc_oracle_jk_dense.restype = ctypes.c_long
+        L.jqc_oracle_jk_bench.argtypes = [ctypes.c_int, dp, dp, ctypes.c_double, ctypes.POINTER(ctypes.c_uint16), ctypes.c_long,
+                                          ctypes.c_int, ctypes.c_int]
+        L.jqc_oracle_jk_bench.restype = ctypes.c_double
         from joltqc_amd.backend.rys import pack_tables  # data file only (numbers), no product code path
         _BLOB = np.array(pack_tables())
         L.jqc_oracle_set_rys(_BLOB.ctypes.data_as(dp))
@@ -80,6 +83,16 @@ def jk_raw(basis, dm, quartets, omega=0.0, do_j=True, do_k=True, nthreads=1):
     lib().jqc_oracle_jk_mt(nao, _dp(basis), n_dm, _dp(dm), _dp(vj), _dp(vk), float(omega or 0.0),
                            q.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), q.shape[0], int(do_j), int(do_k), int(nthreads))
     return vj, vk
+
+
+def jk_bench(basis, dm, quartets, reps=1, omega=0.0, nthreads=1):
+    """bench.py's CPU-baseline leg: ERI blocks + the six contractions of every listed quartet, ``reps`` passes, digested
+    into thread-local blocks (no shared Fock matrix: see jk_oracle.c).  Returns the checksum."""
+    basis = np.ascontiguousarray(basis, dtype=np.float64)
+    dm = np.ascontiguousarray(dm, dtype=np.float64)
+    q = np.ascontiguousarray(quartets, dtype=np.uint16).reshape(-1, 4)
+    return lib().jqc_oracle_jk_bench(dm.shape[-1], _dp(basis), _dp(dm), float(omega or 0.0),
+                                     q.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), q.shape[0], int(reps), int(nthreads))
 
 
 def jk_raw_dense(basis, dm, skip, omega=0.0, do_j=True, do_k=True, cutoff=None, nthreads=None):

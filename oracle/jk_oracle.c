@@ -292,6 +292,62 @@ void jqc_oracle_jk_mt(int nao, const double *basis, int n_dm, const double *dm, 
     }
 }
 
+/*
+ * CPU-baseline leg of bench.py (not a parity path): the same per-quartet work -- eri_block + the six contractions of
+ * 1q1t.cu:423-638 with the real density matrix -- but the six Fock sub-blocks of a quartet go to thread-local stack
+ * arrays and from there into a per-thread checksum, the way a CPU direct-SCF code digests into thread-private Fock
+ * copies: no shared write, no atomic, no O(nao^2) private matrix per thread (256 threads x 2 x 3180^2 doubles would
+ * be 41 GB).  Returns the sum of the per-thread checksums (keeps the work alive); `reps` passes over the list.
+ */
+double jqc_oracle_jk_bench(int nao, const double *basis, const double *dm, double omega, const uint16_t *quartets,
+                           long ntasks, int reps, int nthreads)
+{
+    double total = 0;
+#pragma omp parallel num_threads(nthreads) reduction(+ : total)
+    {
+        double *blk = (double *)malloc(sizeof(double) * NF_MAX * NF_MAX * NF_MAX * NF_MAX);
+        double chk = 0;
+        for (int rep = 0; rep < reps; rep++) {
+#pragma omp for schedule(dynamic, 64) nowait
+            for (long t = 0; t < ntasks; t++) {
+                const int ish = quartets[4 * t], jsh = quartets[4 * t + 1], ksh = quartets[4 * t + 2], lsh = quartets[4 * t + 3];
+                if (ksh > ish || ish < jsh || lsh > ksh) continue;
+                double fac = PI_FAC;
+                if (ish == jsh) fac *= 0.5;
+                if (ksh == lsh) fac *= 0.5;
+                if (ish == ksh && jsh == lsh) fac *= 0.5;
+                const double *bi = basis + ish * STRIDE, *bj = basis + jsh * STRIDE;
+                const double *bk = basis + ksh * STRIDE, *bl = basis + lsh * STRIDE;
+                eri_block(bi, bj, bk, bl, omega, fac, blk);
+                const int li = (int)bi[11], lj = (int)bj[11], lk = (int)bk[11], ll = (int)bl[11];
+                const int nfi = (li + 1) * (li + 2) / 2, nfj = (lj + 1) * (lj + 2) / 2;
+                const int nfk = (lk + 1) * (lk + 2) / 2, nfl = (ll + 1) * (ll + 2) / 2;
+                const int i0 = (int)bi[3], j0 = (int)bj[3], k0 = (int)bk[3], l0 = (int)bl[3];
+                double jij[NF_MAX * NF_MAX] = {0}, jkl[NF_MAX * NF_MAX] = {0}, kik[NF_MAX * NF_MAX] = {0};
+                double kil[NF_MAX * NF_MAX] = {0}, kjk[NF_MAX * NF_MAX] = {0}, kjl[NF_MAX * NF_MAX] = {0};
+                const double *e = blk;
+                for (int i = 0; i < nfi; i++)
+                for (int j = 0; j < nfj; j++)
+                for (int k = 0; k < nfk; k++)
+                for (int l = 0; l < nfl; l++, e++) {
+                    const double v = *e;
+                    const long I = i0 + i, J = j0 + j, K = k0 + k, L = l0 + l;
+                    jkl[k * NF_MAX + l] += v * dm[I + J * nao];
+                    jij[i * NF_MAX + j] += v * dm[K + L * nao];
+                    kik[i * NF_MAX + k] += v * dm[J * nao + L];
+                    kil[i * NF_MAX + l] += v * dm[J * nao + K];
+                    kjk[j * NF_MAX + k] += v * dm[I * nao + L];
+                    kjl[j * NF_MAX + l] += v * dm[I * nao + K];
+                }
+                for (int n = 0; n < NF_MAX * NF_MAX; n++) chk += jij[n] + jkl[n] + kik[n] + kil[n] + kjk[n] + kjl[n];
+            }
+        }
+        total += chk;
+        free(blk);
+    }
+    return total;
+}
+
 void jqc_oracle_jk(int nao, const double *basis, int n_dm, const double *dm, double *vj, double *vk,
                    double omega, const uint16_t *quartets, long ntasks, int do_j, int do_k)
 {

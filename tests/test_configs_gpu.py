@@ -1,0 +1,228 @@
+"""BASELINE configs 4 and 5 at their own sizes, on the GPU (driver: pytest -m gpu).
+
+Config 4 -- "Valinomycin RKS wB97M-V/def2-TZVPP mixed FP32/FP64 (VV10 nlc path)": the 166-atom CHNO stand-in
+(Valinomycin has 168 atoms and its geometry is not in the reference) with def2-TZVPP:
+  * J/K: mixed-precision windows 1e-13 / 1e-7 against pure FP64 (reference bar 1e-7, jqc/pyscf/tests/test_jk.py:176-212),
+    the long-range K-only build that a range-separated hybrid asks for (omega = 0.3) against the independent queue-driven
+    one-quartet-per-lane kernels, tiled == queue for full-range J+K, symmetry;
+  * grid path: meta-GGA rho / vxc (ndim = 5, the tau terms) -- rho and vxc kernels are each other's adjoint, V symmetric,
+    sampled 256-point blocks of rho against the NumPy oracle;
+  * VV10 with more than 2.6e5 NLC points: FP32 inner loop against FP64, the pair sum is symmetric under exchange of the
+    two weight vectors, sampled outer points against the NumPy oracle (reference jqc/backend/dft/vv10.cu:61-111).
+Config 5 -- "Olestra (~450 atoms) RHF/def2-SVP, quartets sharded over ranks with one Fock all-reduce": the 425-atom stand-in
+with def2-SVP: one-rank size-independent properties, and two ranks (one device, gloo) == one rank.
+No CPU oracle finishes a full J/K build at these sizes in seconds, hence properties + independent kernels + sampled oracle
+blocks, as tests/test_jk_fullsize_gpu.py does for 112 atoms.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _queue_kernels(lay):
+    """generate_jk_kernel bound to the queue-driven one-quartet-per-lane kernels (jqc_screen_jk_tasks + jk_1q1t.hip)."""
+    from joltqc_amd.backend import jk as router
+    from joltqc_amd.pyscf import jk as jkmod
+    saved = os.environ.get("JQC_JK_ALGO")
+    os.environ["JQC_JK_ALGO"] = "1q1t"
+    router.gen_jk_kernel.cache_clear()
+    try:
+        return jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
+    finally:
+        if saved is None:
+            os.environ.pop("JQC_JK_ALGO", None)
+        else:
+            os.environ["JQC_JK_ALGO"] = saved
+
+
+def _restore_router():
+    from joltqc_amd.backend import jk as router
+    router.gen_jk_kernel.cache_clear()
+
+
+def test_config4_166_atoms_tzvpp_jk_mixed_precision_and_long_range():
+    import torch
+    import big_check
+    from joltqc_amd.pyscf import jk as jkmod
+    mol, lay, dm = big_check.setup("0166-irregular-nitrogenous", "def2-tzvpp")
+    assert mol.natm == 166 and mol.nao > 3500
+    g = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
+    vj, vk = (x.clone() for x in g(mol, dm, hermi=1))
+    n64 = g.quartet_counts()[0]
+    sc = float(max(vj.abs().max(), vk.abs().max()))
+    assert n64 > 2e10 and torch.isfinite(vj).all() and torch.isfinite(vk).all()
+    assert float((vj - vj.T).abs().max()) < 1e-14 * sc and float((vk - vk.T).abs().max()) < 1e-14 * sc
+    # mixed precision: the reference's windows (estimate in (1e-13, 1e-7] -> FP32 kernel); bar of its own test: 1e-7
+    gm = jkmod.generate_jk_kernel(lay, cutoff_fp64=1e-7, cutoff_fp32=1e-13)
+    mj, mk = gm(mol, dm, hermi=1)
+    assert float((mj - vj).abs().max()) < 1e-7 and float((mk - vk).abs().max()) < 1e-7
+    # what an RSH functional asks of get_jk: long-range K only -- tiled kernels vs the independent queue kernels
+    kk = g(mol, dm, hermi=1, with_j=False, omega=0.3)[1].clone()
+    gq = _queue_kernels(lay)
+    try:
+        qk = gq(mol, dm, hermi=1, with_j=False, omega=0.3)[1]
+        assert float(kk.abs().max()) > 1e-3
+        assert float((kk - qk).abs().max()) < 1e-11 * float(kk.abs().max())
+        # full-range J+K: tiled == queue
+        qj, qk2 = gq(mol, dm, hermi=1)
+        assert float((qj - vj).abs().max()) < 1e-11 * sc and float((qk2 - vk).abs().max()) < 1e-11 * sc
+        assert abs(gq.quartet_counts()[0] - n64) < 1e-4 * n64
+    finally:
+        _restore_router()
+
+
+def _becke_grid(mol, nrad, ntheta):
+    from joltqc_amd.gto import grids as G
+    from joltqc_amd.pyscf import rks
+    g = G.Grids(mol, nrad, ntheta).build()
+    order = rks.arg_group_grids(g.coords)
+    g.coords, g.weights = g.coords[order], g.weights[order]
+    npad = (-len(g.weights)) % 256
+    g.coords = np.vstack([g.coords, np.repeat(g.coords[-1:], npad, axis=0)])
+    g.weights = np.concatenate([g.weights, np.zeros(npad)])
+    return g
+
+
+def test_config4_166_atoms_tzvpp_meta_gga_grid_path_and_vv10():
+    import torch
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import rks
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import dft
+    mol = mole.Mole(atom=mole.read_xyz(os.path.join(ROOT, "joltqc_amd/data/molecules/0166-irregular-nitrogenous.xyz")),
+                    basis="def2-tzvpp")
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    rng = np.random.default_rng(5)
+    nocc = mol.nelectron // 2
+    c = rng.random((mol.nao, nocc)) - 0.5
+    D = c @ c.T / nocc
+    M = rng.random((mol.nao, mol.nao)) - 0.5
+    M = M + M.T
+    g = _becke_grid(mol, 24, 8)                      # 166 x 24 x 128 points
+    n = len(g.weights)
+    assert n > 4.5e5
+    wv = rng.random((5, n)) * g.weights
+    for label, c64, tol in (("fp64", 1e-13, 1e-9), ("mixed", 1e-6, 1e-6)):
+        _, rho_k, vxc_k = rks.generate_rks_kernel(lay, cutoff_fp64=c64, cutoff_fp32=1e-13)
+        rho = rho_k(mol, g, "MGGA", D).cpu().numpy()
+        assert rho.shape == (5, n) and np.isfinite(rho).all()
+        Vx = vxc_k(mol, g, "MGGA", wv).cpu().numpy()
+        assert np.abs(Vx - Vx.T).max() < 1e-12 * np.abs(Vx).max()
+        rho_M = rho_k(mol, g, "MGGA", M).cpu().numpy()
+        # <V, M> = int wv . rho_M with the conventions of reference tests/test_rks.py:185-192 (tau: wv4 * 1/2 * tau-density)
+        lhs, rhs = float((Vx * M).sum()), float((wv * rho_M).sum())
+        assert abs(lhs - rhs) < tol * abs(rhs), (label, lhs, rhs)
+        if label == "fp64":
+            for blk in (0, n // 512, n // 256 - 2):
+                sl = slice(blk * 256, blk * 256 + 256)
+                ref = dft.eval_rho(lay, g.coords[sl], D, "MGGA")
+                assert np.abs(rho[:, sl] - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()), blk
+
+    # ---- VV10 sums at N > 2.6e5 (the NLC grid of this molecule at (50,194) would hold ~1e6 points): 262 144 points of the grid
+    N = 262144 + 256
+    pick = np.sort(rng.choice(n, N, replace=False))
+    xyz = torch.from_numpy(g.coords[pick].T.copy()).cuda()
+    dens = rng.random(N) * 0.3 + 1e-3
+    W0 = torch.from_numpy(np.sqrt(0.01 + 4.0 * np.pi / 3.0 * dens)).cuda()
+    K = torch.from_numpy(1.5 * dens ** (1.0 / 6.0)).cuda()
+    u = torch.from_numpy(rng.random(N) * 1e-3).cuda()
+    v = torch.from_numpy(rng.random(N) * 1e-3).cuda()
+    outer = torch.cat([xyz, W0[None], K[None]]).contiguous()
+    sums = {}
+    for name, w, fp32 in (("u32", u, True), ("u64", u, False), ("v64", v, False)):
+        inner = torch.cat([xyz, W0[None], K[None], w[None]]).contiguous()
+        sums[name] = rks.vv10_sums(outer, inner, fp32)
+    F64, F32 = sums["u64"], sums["u32"]
+    assert float((F32 - F64).abs().max()) < 2e-5 * float(F64.abs().max())            # FP32 inner loop, FP64 accumulation
+    # exchange symmetry of the pair kernel 1 / (g g' (g + g')): sum_i v_i F_i[u] = sum_i u_i F_i[v]
+    a, b = float((v * sums["u64"][0]).sum()), float((u * sums["v64"][0]).sum())
+    assert abs(a - b) < 1e-12 * abs(a), (a, b)
+    # sampled outer points against the NumPy oracle (dense double loop)
+    idx = np.array([0, 1, 255, 256, N // 2, N - 1])
+    co = g.coords[pick]
+    Fr, Ur, Wr = dft.vv10_kernel(co[idx], co, W0.cpu().numpy()[idx], K.cpu().numpy()[idx], W0.cpu().numpy(), K.cpu().numpy(),
+                                 u.cpu().numpy())
+    got = F64.cpu().numpy()[:, idx]
+    for ref, val in ((Fr, got[0]), (Ur, got[1]), (Wr, got[2])):             # (both carry the -1.5 of vv10.cu:114 on F)
+        assert np.abs(val - ref).max() < 1e-10 * np.abs(ref).max()
+
+
+def _rank_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # two ranks on one GPU: RCCL refuses duplicate devices
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import big_check
+    from joltqc_amd.pyscf import jk as jkmod
+    mol, lay, dm = big_check.setup("0425-globular-nitrogenous", "def2-svp")
+    g = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13, shard=(rank, world))
+    t = time.time()
+    vj, vk = g(mol, dm, hermi=1)
+    torch.cuda.synchronize()
+    n64 = g.quartet_counts()[0]
+    if rank == 0:
+        torch.save((vj.cpu(), vk.cpu()), os.path.join("/tmp", f"jqc_cfg5_{port}.pt"))
+    q.put((rank, n64, time.time() - t))
+    dist.destroy_process_group()
+
+
+def test_config5_425_atoms_svp_one_rank_and_two_ranks():
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    import big_check
+    from joltqc_amd.pyscf import jk as jkmod
+    mol, lay, dm = big_check.setup("0425-globular-nitrogenous", "def2-svp")
+    assert mol.natm == 425 and mol.nao > 4400
+    g = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
+    vj, vk = (x.clone() for x in g(mol, dm, hermi=1))
+    n_all = g.quartet_counts()[0]
+    sc = float(max(vj.abs().max(), vk.abs().max()))
+    assert n_all > 2.5e10 and torch.isfinite(vj).all() and torch.isfinite(vk).all()
+    assert float((vj - vj.T).abs().max()) < 1e-14 * sc and float((vk - vk.T).abs().max()) < 1e-14 * sc
+    # independent algorithm at full size
+    gq = _queue_kernels(lay)
+    try:
+        qj, qk = gq(mol, dm, hermi=1)
+        assert float((qj - vj).abs().max()) < 1e-11 * sc and float((qk - vk).abs().max()) < 1e-11 * sc
+        assert abs(gq.quartet_counts()[0] - n_all) < 1e-4 * n_all
+    finally:
+        _restore_router()
+    # launch geometry: one ket pair per workgroup (the launch-size guard lengthens the chunks where 2^24 workgroups would overflow)
+    kc, ns = jkmod.KCHUNK_MAX, jkmod.NSPLIT_MAX
+    try:
+        jkmod.KCHUNK_MAX, jkmod.NSPLIT_MAX = 1, 1
+        j2, k2 = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)(mol, dm, hermi=1)
+    finally:
+        jkmod.KCHUNK_MAX, jkmod.NSPLIT_MAX = kc, ns
+    assert float((j2 - vj).abs().max()) < 1e-12 * sc and float((k2 - vk).abs().max()) < 1e-12 * sc
+    del qj, qk, j2, k2, gq
+    torch.cuda.empty_cache()
+    # ---- two ranks share the quartets (cost-aware class / strip split), ONE all-reduce of the raw [vj; vk] (398 MB)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    path = os.path.join("/tmp", f"jqc_cfg5_{port}.pt")
+    sj, sk = torch.load(path)
+    os.remove(path)
+    assert float((sj.cuda() - vj).abs().max()) < 1e-11 * sc and float((sk.cuda() - vk).abs().max()) < 1e-11 * sc
+    assert res[0][1] + res[1][1] == n_all                       # every dispatched quartet on exactly one rank
+    assert min(res[0][1], res[1][1]) > 0.4 * n_all              # balanced to 60 / 40 or better
