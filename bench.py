@@ -287,6 +287,7 @@ def main():
         vj, vk = get_jk(mol, dm, hermi=1)
     barrier()
     dt = time.perf_counter() - t0
+    dt_rank = dt
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     nq = torch.tensor([float(n64 + n32), float(total_flops)], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -310,6 +311,28 @@ def main():
         tm.setdefault(ang, []).append(e0.elapsed_time(e1))
     tm = {a: float(np.mean(v)) for a, v in tm.items()}
     serial_ms = sum(tm.values())
+    per_rank = None
+    if world > 1:
+        # diagnosability of the scaling curve: what every rank did -- its kernels' serial time, its quartets, the one Fock
+        # all-reduce (timed alone on a buffer of the call's size), its wall time for the timed steps
+        buf = torch.zeros((2, layout.nao, layout.nao), dtype=torch.float64, device="cuda")
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ta = time.perf_counter()
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - ta) / 3 * 1e3
+        mine = torch.tensor([serial_ms, float(n64 + n32), ar_ms, dt_rank / steps * 1e3], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [[float(x) for x in t.tolist()] for t in allr]
+        ks = [r[0] for r in rows]
+        per_rank = {"kernel_ms_sum": [round(r[0], 3) for r in rows], "quartets": [r[1] for r in rows],
+                    "allreduce_ms": [round(r[2], 3) for r in rows], "step_ms": [round(r[3], 3) for r in rows],
+                    "kernel_imbalance_max_over_mean": max(ks) / (sum(ks) / world) if sum(ks) > 0 else None,
+                    "allreduce_bytes": int(buf.numel() * 8)}
     if rank == 0:
         from joltqc_amd.backend import jk as router
         ms = dt / steps * 1e3
@@ -341,6 +364,8 @@ def main():
                                          "achieved": flops_by_ang.get(best, 0) / tm[best] / 1e9,
                                          "frac": flops_by_ang.get(best, 0) / tm[best] / 1e9 / FP64_VALU_PEAK_TFLOPS}},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         tr = committed_traffic(kname) if args.workload == DEFAULT_WORKLOAD else None
         if tr:
             out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")

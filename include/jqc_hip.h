@@ -46,6 +46,13 @@ extern "C" {
 #define JQC_VARIANT_ECAP(code) ((code) << 16) /* row-lane mode: integrals held per lane and chunk capped at 64 (0), 32 (1), 16 (2)
                                       or 48 (3): smaller chunks re-read the TRR array from LDS but keep the lane out of scratch */
 
+#define JQC_VARIANT_ORED (1 << 18)  /* row-lane mode: owner reduction -- the outputs that are sums over the lanes of a quartet go through
+                                      a per-wave scratch area (aliasing the TRR array) and are added to the LDS Fock tiles once per
+                                      quartet by one owner lane each, instead of one same-address ds_add_f64 per lane */
+#define JQC_VARIANT_PAROOT (1 << 19) /* row-lane mode: a phase-A job = (quartet, root), three axes per job (Rys root evaluated once) */
+#define JQC_VARIANT_NDM2 (1 << 20)  /* two density matrices contracted per integral evaluation (D / Fock tiles of both in LDS); the
+                                      kernel walks n_dm in pairs.  Lane-per-quartet builds and owner-reduction builds only */
+
 const char* jqc_last_error(void);
 const char* jqc_version(void);
 /* tag (hash of the kernel sources) embedded in every cached code-object name; valid after jqc_set_kernel_dirs */

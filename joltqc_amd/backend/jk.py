@@ -52,13 +52,33 @@ def class_key(ang):
     return str(1000 * li + 100 * lj + 10 * lk + ll)
 
 
+VARIANT_ORED, VARIANT_PAROOT, VARIANT_NDM2 = 1 << 18, 1 << 19, 1 << 20     # include/jqc_hip.h
+
+
+def lanes_per_quartet(ang, v):
+    """Row lanes T of one quartet under variant ``v`` (j components in registers: nf_i, otherwise nf_i * nf_j)."""
+    nf = lambda l: (l + 1) * (l + 2) // 2
+    return nf(ang[0]) if (v & 0x800) else nf(ang[0]) * nf(ang[1])
+
+
+def supports_ndm2(ang, v):
+    """May variant ``v`` of class ``ang`` be built for two density matrices per integral evaluation (NDM = 2)?
+    Lane-per-quartet builds (plain contraction order) and row-lane builds with the owner reduction (a quartet inside one wave)."""
+    a = v & 0xf
+    if a == _lib.ALGO_TILE1Q:
+        return not (v & 0xc000)
+    if a == _lib.ALGO_TILE:
+        return bool(v & VARIANT_ORED) and lanes_per_quartet(ang, v) <= 64
+    return False
+
+
 def forced_variant(ang, v):
     """Variant code ``v`` adjusted to what class ``ang`` supports: lane-per-quartet only where the integral block fits,
     the wave-local variant only where a quartet fits one wave."""
     if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > TILE1Q_FORCE_MAX:
         return _lib.ALGO_TILE
     if (v & 0xf) == _lib.ALGO_TILE1Q:
-        v &= ~0x30000                                 # integral chunks: row-lane mode only
+        v &= ~(0x30000 | VARIANT_ORED | VARIANT_PAROOT)   # integral chunks, owner reduction, per-root phase A: row-lane mode only
     if (v & 0xf) != _lib.ALGO_TILE1Q:
         v &= ~0xf000                                  # several ket pairs per iteration, strided queue, row-ordered contraction:
                                                       # lane-per-quartet mode only
@@ -101,8 +121,11 @@ def _lds_overflow(err):
 
 
 def kernel_key(ang, do_j, do_k, rys_lr, fp32, algo):
-    """Name of one class-kernel BUILD (same string the library keys its code objects on, minus tile widths and source tag)."""
-    return "jk%d_%d%d%d%d_j%dk%d_lr%d_%s" % (int(algo), *ang, int(do_j), int(do_k), int(rys_lr), "f32" if fp32 else "f64")
+    """Name of one class-kernel BUILD: the string the library keys its code objects on (tile widths included: other widths are
+    other code objects with other register allocations), minus the source tag."""
+    from ..constants import TILE_WIDTHS
+    return "jk%d_%d%d%d%d_j%dk%d_lr%d_%s_t%s" % (int(algo), *ang, int(do_j), int(do_k), int(rys_lr), "f32" if fp32 else "f64",
+                                                ".".join(str(int(w)) for w in TILE_WIDTHS))
 
 
 _MANIFEST = os.path.join(os.path.dirname(_SCHEME), "verified_kernels.json")
@@ -160,9 +183,13 @@ def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None
             # pairs per iteration, then the plain row-lane kernel.  Anything else (compiler error, missing source) is raised.
             if not _lds_overflow(e):
                 raise
-            if algo & 0x3000:
+            if (algo & VARIANT_NDM2) and (algo & 0xf) != _lib.ALGO_TILE1Q:
+                algo &= ~VARIANT_NDM2                 # the tiles of two density matrices do not fit: one matrix per pass
+            elif algo & 0x3000:
                 nks = (algo >> 12) & 3
                 algo = (algo & ~0x3000) | ((nks - 1) << 12)
+            elif algo & VARIANT_NDM2:
+                algo &= ~VARIANT_NDM2
             elif (algo & 0xf) != _lib.ALGO_TILE or (algo & 0xc00):
                 algo = _lib.ALGO_TILE | (algo & 0x1f0)
             else:

@@ -535,7 +535,8 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
     }
     if (const char* extra = getenv("JQC_EXTRA_DEFS"))
         for (const char* c = extra; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
-    for (const char* c = "build-policy:karg-reload-iff-scratch"; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+    // (bump when the build logic of jqc_gen_jk_kernel changes: MINW rebuild loop, ECAP codes, KARG_RELOAD choice, variant bits)
+    for (const char* c = "build-policy-r3:karg-reload-iff-scratch,ored,paroot,ndm2"; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
     // compiler version and option set: register allocation decides which builds pass the gates, so code
     // objects of another hiprtc are other builds -- not reused from the cache, not covered by the verified manifest
     {
@@ -595,6 +596,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     const int v_nks = (algo_variant >> 12) & 3;
     const int v_qil = (algo_variant >> 14) & 1, v_cord = (algo_variant >> 15) & 1;
     const int v_ecap = (algo_variant >> 16) & 3;
+    const int v_ored = (algo_variant >> 18) & 1, v_paroot = (algo_variant >> 19) & 1, v_ndm2 = (algo_variant >> 20) & 1;
     if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
     if (!do_j && !do_k) return fail(-1, "need do_j or do_k");
@@ -628,6 +630,9 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
         if (v_qil) d.push_back("-DQIL=1");
         if (v_cord) d.push_back("-DCORD=1");
         if (v_ecap) d.push_back(std::string("-DECAP=") + (v_ecap == 1 ? "32" : v_ecap == 2 ? "16" : "48"));
+        if (v_ored) d.push_back("-DORED=1");
+        if (v_paroot) d.push_back("-DPAROOT=1");
+        if (v_ndm2) d.push_back("-DNDM=2");
         if (tiled) {
             // Builds that spill vector registers to scratch also re-read the staging pointers from the kernarg segment
             // (KARG_RELOAD in jk_tile.hip: ~45 fewer SGPRs spilled to VGPR lanes); builds without scratch keep the

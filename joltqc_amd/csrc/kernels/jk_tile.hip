@@ -58,6 +58,39 @@ constexpr int NQ = TSI * TSJ * TSK * TSL;
                     // small ket block (few integrals per (ci,cj) lane) the LDS reads of phase B are shared by nf_j times more
                     // products and K_ik / K_il / J_ij need no cross-lane sum at all.
 #endif
+#ifdef CTWO
+#define CTWO_ CTWO
+#else
+#define CTWO_ 0
+#endif
+#ifdef CORD
+#define CORD_ CORD
+#else
+#define CORD_ 0
+#endif
+#ifdef STAGE_ALL
+#define STAGE_ALL_ STAGE_ALL
+#else
+#define STAGE_ALL_ 0
+#endif
+#ifndef NDM
+#define NDM 1       // density matrices contracted against ONE evaluation of the integrals (1 or 2): the kernel walks the n_dm
+                    // matrices of a call in groups of NDM; D and Fock tiles of a group live in LDS side by side.  Reference:
+                    // every density matrix is contracted against the same integral block (jk/1q1t.cu:423-638, 1qnt.cu:488).
+#endif
+#ifndef ORED
+#define ORED 0      // row-lane mode with the j components in registers (CJR): the three outputs that are summed over the bra
+                    // component i -- J_kl, K_jk, K_jl, i.e. over the LANES of a quartet -- are not added to the LDS Fock tiles by
+                    // every lane (all T lanes of a quartet, and the neighbouring quartets of the wave, hit the SAME address in
+                    // one instruction: ds_add_f64 serialises them, ~140 cycles per instruction), but written to a per-wave
+                    // scratch area [value][lane] (conflict-free), summed by one OWNER lane per value, and added once per
+                    // quartet with all lanes of the instruction on different addresses.  The scratch aliases the TRR array,
+                    // which is dead during the contraction.
+#endif
+#ifndef PAROOT
+#define PAROOT 0    // row-lane mode: a phase-A job = (quartet, root) and runs the transfer recurrence of all three axes, so the
+                    // Rys root and the primitive prefactors are evaluated once instead of three times
+#endif
 constexpr int EJ = CJR ? NFJ : 1;                    // bra j components held per lane
 constexpr int T = CJR ? NFI : NFI * NFJ;
 #ifndef TBLOCK
@@ -70,7 +103,8 @@ constexpr int T = CJR ? NFI : NFI * NFJ;
 #endif
 constexpr int NWAVE = TBLOCK / 64;
 constexpr int GW = T <= 64 ? 64 / T : 0;          // quartets per wave (WSYNC)
-constexpr int G = WSYNC ? NWAVE * GW : TBLOCK / T;
+constexpr bool WMAP = WSYNC || (ORED && !TILE_1Q && T <= 64);     // lane -> quartet map with whole quartets per wave
+constexpr int G = WMAP ? NWAVE * GW : TBLOCK / T;
 #ifndef ECAP
 #define ECAP 64
 #endif
@@ -112,9 +146,38 @@ constexpr int NJOB = G * 3 * NROOTS;                                      // pha
 #ifndef TRR_DOUBLE_BUFFER
 #define TRR_DOUBLE_BUFFER 0
 #endif
-constexpr int NBUF = (TRR_DOUBLE_BUFFER && !WSYNC && 2 * G * NROOTS * 3 * NT2 * (int)sizeof(real) <= ST_LDS_MAX) ? 2 : 1;
+#ifndef TPAD
+#define TPAD 0      // extra reals per quartet slot of the TRR array (bank spread of the phase-B reads across quartets)
+#endif
+constexpr int TRR_SLOT = NROOTS * 3 * NT2 + TPAD;                           // reals per quartet slot
+constexpr bool USE_ORED = ORED && !TILE_1Q && T <= 64;
+constexpr int NBUF = (TRR_DOUBLE_BUFFER && !WSYNC && !USE_ORED && 2 * G * TRR_SLOT * (int)sizeof(real) <= ST_LDS_MAX) ? 2 : 1;
+// owner reduction (ORED): values per lane and step, scratch rows of RSTR doubles (odd: the owner lanes read column-wise)
+// rows: J_kl [CW * NFL], K_jk [EJ * CW], K_jl [EJ * NFL]; lane = (ci, cj) form in addition K_ik [CW], K_il [NFL] (summed over cj)
+constexpr int NE0 = DO_J ? CW * NFL : 0, NE1 = DO_K ? EJ * CW : 0, NE2 = DO_K ? EJ * NFL : 0;
+constexpr int NE3 = (DO_K && !CJR) ? CW : 0, NE4 = (DO_K && !CJR) ? NFL : 0, NPART = NE0 + NE1 + NE2 + NE3 + NE4;
+constexpr int RSTR = 66;
+constexpr int RDBL = 8 / (int)sizeof(real);                                 // reals per double
+constexpr int RG_MIN = NPART < 16 ? NPART : 16;                              // rows the scratch of a wave holds at least
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+// reals of the TRR array that belong to one wave (WSYNC: its GW slots; otherwise a quarter of the whole array)
+constexpr int WREG0 = WMAP ? GW * TRR_SLOT : (G * TRR_SLOT + NWAVE - 1) / NWAVE;
+constexpr int WREG = USE_ORED ? ((cmax(WREG0, RG_MIN * RSTR * RDBL) + 3) & ~3) : WREG0;
+constexpr int ST_LEN = USE_ORED ? cmax(NWAVE * WREG, NBUF * G * TRR_SLOT) : NBUF * G * TRR_SLOT;
+constexpr int RG = cmin(cmin(WREG / (RSTR * RDBL), NPART), 64);
+constexpr int NPASS = RG > 0 ? (NPART + RG - 1) / RG : 0;
+constexpr int NH = RG > 0 ? 64 / RG : 1;                                    // owner lanes per scratch row (they split the quartets)
+// offset of quartet slot `sl` in the TRR array
+__device__ __forceinline__ int trr_off(const int sl)
+{
+    constexpr int gw = GW > 0 ? GW : 1;
+    return WMAP ? (sl / gw) * WREG + (sl % gw) * TRR_SLOT : sl * TRR_SLOT;
+}
 static_assert(!WSYNC || (T <= 64 && !TILE_1Q), "WSYNC needs a quartet to fit one wave");
 static_assert(!CJR || !TILE_1Q, "CJR is a variant of the row-lane mode");
+static_assert(NDM == 1 || NDM == 2, "density matrices per integral evaluation");
+static_assert(NDM == 1 || ((TILE_1Q || USE_ORED) && !CTWO_ && !CORD_ && !STAGE_ALL_), "NDM > 1: lane-per-quartet or owner-reduction builds");
 #if WSYNC
 // ordering of LDS traffic inside one wave is kept by the hardware (one in-order DS queue per wave); the compiler only
 // has to keep the program order of the accesses
@@ -375,10 +438,11 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     // NKS ket tile pairs are staged and screened per iteration (lane-per-quartet mode only): classes with few candidates
     // per tile pair fill the 256 lanes from several ket pairs; queue entry = candidate id | ket slot << KS_SHIFT
     __shared__ unsigned short s_act[NKS * NQ];  // their candidate ids, appended wave by wave
-    __shared__ real sDij[WJ * WI], sDkl[NKS * WL * WK], sDik[NKS * WI * WK], sDil[NKS * WI * WL], sDjk[NKS * WJ * WK], sDjl[NKS * WJ * WL];
-    __shared__ double sJij[(TILE_1Q ? JREP : 1) * WJ * WI], sJkl[NKS * WL * WK], sKik[NKS * WI * WK], sKil[NKS * WI * WL], sKjk[NKS * WJ * WK], sKjl[NKS * WJ * WL];
+    // (NDM > 1: [dm][ket slot][tile])
+    __shared__ real sDij[NDM * WJ * WI], sDkl[NDM * NKS * WL * WK], sDik[NDM * NKS * WI * WK], sDil[NDM * NKS * WI * WL], sDjk[NDM * NKS * WJ * WK], sDjl[NDM * NKS * WJ * WL];
+    __shared__ double sJij[NDM * (TILE_1Q ? JREP : 1) * WJ * WI], sJkl[NDM * NKS * WL * WK], sKik[NDM * NKS * WI * WK], sKil[NDM * NKS * WI * WL], sKjk[NDM * NKS * WJ * WK], sKjl[NDM * NKS * WJ * WL];
 #if !TILE_1Q
-    __shared__ real sT[NBUF * G * NROOTS * 3 * NT2];
+    __shared__ __attribute__((aligned(16))) real sT[ST_LEN];
 #endif
     // shell rows of the four tiles and per-primitive-pair prefactors {c_a c_b K_ab, 1/(a+b), a+b}:
     // every exp / reciprocal of the pair prefactors is evaluated once per tile pair, not once per quartet
@@ -390,6 +454,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #if STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -445,14 +510,14 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             for (int u = 0; u < NRYS; u++) rrys[u] = tid + u * TBLOCK < RYS_TAB ? rys_cheb[tid + u * TBLOCK] : real(0);
         }
 #if DO_J
-        for (int n = tid; n < (TILE_1Q ? JREP : 1) * WJ * WI; n += TBLOCK) sJij[n] = 0;
-        for (int n = tid; n < NKS * WL * WK; n += TBLOCK) sJkl[n] = 0;
+        for (int n = tid; n < NDM * (TILE_1Q ? JREP : 1) * WJ * WI; n += TBLOCK) sJij[n] = 0;
+        for (int n = tid; n < NDM * NKS * WL * WK; n += TBLOCK) sJkl[n] = 0;
 #endif
 #if DO_K
-        for (int n = tid; n < NKS * WI * WK; n += TBLOCK) sKik[n] = 0;
-        for (int n = tid; n < NKS * WI * WL; n += TBLOCK) sKil[n] = 0;
-        for (int n = tid; n < NKS * WJ * WK; n += TBLOCK) sKjk[n] = 0;
-        for (int n = tid; n < NKS * WJ * WL; n += TBLOCK) sKjl[n] = 0;
+        for (int n = tid; n < NDM * NKS * WI * WK; n += TBLOCK) sKik[n] = 0;
+        for (int n = tid; n < NDM * NKS * WI * WL; n += TBLOCK) sKil[n] = 0;
+        for (int n = tid; n < NDM * NKS * WJ * WK; n += TBLOCK) sKjk[n] = 0;
+        for (int n = tid; n < NDM * NKS * WJ * WL; n += TBLOCK) sKjl[n] = 0;
 #endif
         if (tid < 2) s_nact[tid] = 0;
         if (tid < (TSI + TSJ) * BASIS_STRIDE) sBas[tid] = rb;
@@ -470,13 +535,11 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     STAMP(1);
 
 #if !TILE_1Q
-#if WSYNC
-    const int qslot = lane / T, slot = wave * GW + qslot, t = lane - qslot * T;
-    const bool lane_on = qslot < GW;
-#else
-    const int slot = tid / T, t = tid - slot * T;
-    const bool lane_on = slot < G;
-#endif
+    // WMAP: whole quartets per wave (wave-local steps and / or the owner reduction); otherwise quartets packed over the workgroup
+    const int qslot = WMAP ? lane / T : 0;
+    const int slot = WMAP ? wave * GW + qslot : tid / T;
+    const int t = WMAP ? lane - qslot * T : tid - slot * T;
+    const bool lane_on = WMAP ? qslot < GW : slot < G;
 #if CJR
     const int ci = t, cj = 0;
 #else
@@ -490,9 +553,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     int parity = 0;
 
 #if KARG_RELOAD
-    for (int idm = 0; idm < kargs()->n_dm; idm++) {
+    for (int idm = 0; idm < kargs()->n_dm; idm += NDM) {
 #else
-    for (int idm = 0; idm < n_dm; idm++) {
+    for (int idm = 0; idm < n_dm; idm += NDM) {
         const real* __restrict__ D = dm + idm * nao2;
 #endif
 #if DO_J
@@ -502,10 +565,16 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             const KArgs AS4* kd = kargs();
             const int nao = kd->nao;
             const real* __restrict__ D = kd->dm + idm * ((size_t)nao * nao);
+            const int ndm_here = kd->n_dm - idm;
+#else
+            const int ndm_here = n_dm - idm;
 #endif
-            TileRegs<WJ, WI> r;
-            tile_load(r, D, nao, j0, i0, tid);
-            tile_store(sDij, r, tid);
+            TileRegs<WJ, WI> r[NDM];
+#pragma unroll
+            for (int dmi = 0; dmi < NDM; dmi++)       // (a group's missing matrix reads as zero: nao = 0 fails every bounds test)
+                tile_load(r[dmi], D + (dmi < ndm_here ? dmi : 0) * ((size_t)nao * nao), dmi < ndm_here ? nao : 0, j0, i0, tid);
+#pragma unroll
+            for (int dmi = 0; dmi < NDM; dmi++) tile_store(sDij + dmi * (WJ * WI), r[dmi], tid);
         }
         STAMP(2);
 #endif
@@ -666,19 +735,31 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 const real* __restrict__ ppk = pair_tab + (size_t)tpair_pp[kl0 + kt + ks] * 27;
 #pragma unroll
                 for (int u = 0; u < NPK; u++) rpk[u] = tid + u * TBLOCK < TSK * TSL * 27 ? ppk[tid + u * TBLOCK] : real(0);
+#if KARG_RELOAD
+                const int ndm_here = ka->n_dm - idm;
+#else
+                const int ndm_here = n_dm - idm;
+#endif
 #if DO_J
-                TileRegs<WL, WK> rkl;
-                tile_load(rkl, D, nao, l0, k0, tid);
+                TileRegs<WL, WK> rkl[NDM];
+#pragma unroll
+                for (int dmi = 0; dmi < NDM; dmi++)
+                    tile_load(rkl[dmi], D + (dmi < ndm_here ? dmi : 0) * ((size_t)nao * nao), dmi < ndm_here ? nao : 0, l0, k0, tid);
 #endif
 #if DO_K
-                TileRegs<WI, WK> rik;
-                TileRegs<WI, WL> ril;
-                TileRegs<WJ, WK> rjk;
-                TileRegs<WJ, WL> rjl;
-                tile_load(rik, D, nao, i0, k0, tid);
-                tile_load(ril, D, nao, i0, l0, tid);
-                tile_load(rjk, D, nao, j0, k0, tid);
-                tile_load(rjl, D, nao, j0, l0, tid);
+                TileRegs<WI, WK> rik[NDM];
+                TileRegs<WI, WL> ril[NDM];
+                TileRegs<WJ, WK> rjk[NDM];
+                TileRegs<WJ, WL> rjl[NDM];
+#pragma unroll
+                for (int dmi = 0; dmi < NDM; dmi++) {
+                    const real* __restrict__ Dd = D + (dmi < ndm_here ? dmi : 0) * ((size_t)nao * nao);
+                    const int naod = dmi < ndm_here ? nao : 0;
+                    tile_load(rik[dmi], Dd, naod, i0, k0, tid);
+                    tile_load(ril[dmi], Dd, naod, i0, l0, tid);
+                    tile_load(rjk[dmi], Dd, naod, j0, k0, tid);
+                    tile_load(rjl[dmi], Dd, naod, j0, l0, tid);
+                }
 #endif
                 STAMP(3);
                 // ---- per-quartet screening of the NQ candidates of the tile pair (wave64 ballots); every wave appends
@@ -721,15 +802,18 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma unroll
                 for (int u = 0; u < NPK; u++)
                     if (tid + u * TBLOCK < TSK * TSL * 27) sPK[ks * (TSK * TSL * 27) + tid + u * TBLOCK] = rpk[u];
+#pragma unroll
+                for (int dmi = 0; dmi < NDM; dmi++) {
 #if DO_J
-                tile_store(sDkl + ks * (WL * WK), rkl, tid);
+                    tile_store(sDkl + (dmi * NKS + ks) * (WL * WK), rkl[dmi], tid);
 #endif
 #if DO_K
-                tile_store(sDik + ks * (WI * WK), rik, tid);
-                tile_store(sDil + ks * (WI * WL), ril, tid);
-                tile_store(sDjk + ks * (WJ * WK), rjk, tid);
-                tile_store(sDjl + ks * (WJ * WL), rjl, tid);
+                    tile_store(sDik + (dmi * NKS + ks) * (WI * WK), rik[dmi], tid);
+                    tile_store(sDil + (dmi * NKS + ks) * (WI * WL), ril[dmi], tid);
+                    tile_store(sDjk + (dmi * NKS + ks) * (WJ * WK), rjk[dmi], tid);
+                    tile_store(sDjl + (dmi * NKS + ks) * (WJ * WL), rjl[dmi], tid);
 #endif
+                }
             }
 #endif  // STAGE_ALL
 #undef tid
@@ -855,13 +939,25 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
                 STAMP(11);          // (diagnostic) integral evaluation of this batch
                 const int iA = a * NFI, jA = b * NFJ, kA = c * NFK, lA = d * NFL;
-                // ket-slot views of the ket-dependent tiles
-                const real* sDkl_q = sDkl + ks * (WL * WK); const real* sDik_q = sDik + ks * (WI * WK);
-                const real* sDil_q = sDil + ks * (WI * WL); const real* sDjk_q = sDjk + ks * (WJ * WK);
-                const real* sDjl_q = sDjl + ks * (WJ * WL);
-                double* sJkl_q = sJkl + ks * (WL * WK); double* sKik_q = sKik + ks * (WI * WK);
-                double* sKil_q = sKil + ks * (WI * WL); double* sKjk_q = sKjk + ks * (WJ * WK);
-                double* sKjl_q = sKjl + ks * (WJ * WL);
+#if NDM > 1
+#pragma unroll 1
+                for (int dmi = 0; dmi < NDM; dmi++) {
+#else
+                {
+                constexpr int dmi = 0;
+#endif
+                // views of this density matrix's tiles: D_ij / J_ij, and the ket slot of the ket-dependent ones
+                const real* const sDij_v = sDij + dmi * (WJ * WI);
+                double* const sJij_v = sJij_r + dmi * ((TILE_1Q ? JREP : 1) * WJ * WI);
+                const real* sDkl_q = sDkl + (dmi * NKS + ks) * (WL * WK); const real* sDik_q = sDik + (dmi * NKS + ks) * (WI * WK);
+                const real* sDil_q = sDil + (dmi * NKS + ks) * (WI * WL); const real* sDjk_q = sDjk + (dmi * NKS + ks) * (WJ * WK);
+                const real* sDjl_q = sDjl + (dmi * NKS + ks) * (WJ * WL);
+                double* sJkl_q = sJkl + (dmi * NKS + ks) * (WL * WK); double* sKik_q = sKik + (dmi * NKS + ks) * (WI * WK);
+                double* sKil_q = sKil + (dmi * NKS + ks) * (WI * WL); double* sKjk_q = sKjk + (dmi * NKS + ks) * (WJ * WK);
+                double* sKjl_q = sKjl + (dmi * NKS + ks) * (WJ * WL);
+                {
+                const real* const sDij = sDij_v;          // (shadow the arrays: the code below is written for one matrix)
+                double* const sJij_r = sJij_v;
 #if CTWO
                 {
                     // ---- sweep 1: outputs of row i (J_ij, K_ik, K_il); live: D_kl, D_jl, D_jk
@@ -1121,6 +1217,8 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
 #endif
             #endif  // CORD
+                }
+                }
                 STAMP(12);          // (diagnostic) contraction + LDS atomics of this batch
 }
 #if ABL & 2
@@ -1138,7 +1236,82 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 const int ip = cmb % npi; cmb /= npi;
                 const int lp = cmb % npl;
                 const int kp = cmb / npl;
-                real* __restrict__ buf = sT + (NBUF > 1 ? (m & 1) : 0) * (G * NROOTS * 3 * NT2);
+                real* __restrict__ buf = sT + (NBUF > 1 ? (m & 1) : 0) * (G * TRR_SLOT);
+#if PAROOT
+#if WSYNC
+                for (int job = lane; job < GW * NROOTS; job += 64) {
+                    const int sl = job / NROOTS, r = job - sl * NROOTS;
+                    const int sa = wave * GW + sl;
+#else
+                for (int job = tid; job < G * NROOTS; job += TBLOCK) {
+                    const int sa = job / NROOTS, r = job - sa * NROOTS;
+#endif
+                    const int qa = sa * per + step;
+                    if (qa >= nact) continue;
+                    const int qd = s_act[qa];
+                    const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
+                    const real* bi = sBas + a * BASIS_STRIDE;
+                    const real* bj = sBas + OFF_J + b * BASIS_STRIDE;
+                    const real* bk = sBas + OFF_K + c * BASIS_STRIDE;
+                    const real* bl = sBas + OFF_L + d * BASIS_STRIDE;
+                    const real* pb = sPB + (a * TSJ + b) * 27 + (ip * 3 + jp) * 3;
+                    const real* pk = sPK + (c * TSL + d) * 27 + (kp * 3 + lp) * 3;
+                    const real ckcl = pk[0], inv_akl = pk[1], akl = pk[2];
+                    const real cicj = pb[0], inv_aij = pb[1], aij = pb[2];
+                    const real al_akl = bl[5 + 2 * lp] * inv_akl, aj_aij = bj[5 + 2 * jp] * inv_aij;
+                    const real rijv[3] = {bj[0] - bi[0], bj[1] - bi[1], bj[2] - bi[2]};
+                    const real rklv[3] = {bl[0] - bk[0], bl[1] - bk[1], bl[2] - bk[2]};
+                    const real rpqv[3] = {rijv[0] * aj_aij + bi[0] - rklv[0] * al_akl - bk[0],
+                                          rijv[1] * aj_aij + bi[1] - rklv[1] * al_akl - bk[1],
+                                          rijv[2] * aj_aij + bi[2] - rklv[2] * al_akl - bk[2]};
+                    const real rr = rpqv[0] * rpqv[0] + rpqv[1] * rpqv[1] + rpqv[2] * rpqv[2];
+                    const real sinv = fast_rsqrt(aij + akl);
+                    const real inv = sinv * sinv;
+                    const real theta = aij * akl * inv;
+                    real t2, wt;
+                    rys_root_one(rr, theta, omega, r, cheb_tab, rys_large, t2, wt);
+                    const real rt_aa = t2 * inv;
+                    const real rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
+                    const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
+                    const real b01 = real(0.5) * inv_akl * (real(1) - rt_akl);
+                    const real b00 = real(0.5) * rt_aa;
+                    real fac = real(34.98683665524972497);
+                    {
+                        const int ish = ish0 + a, jsh = jsh0 + b, ksh = ksh0 + c, lsh = lsh0 + d;
+                        if (ish == jsh) fac *= real(0.5);
+                        if (ksh == lsh) fac *= real(0.5);
+                        if (ish == ksh && jsh == lsh) fac *= real(0.5);
+                    }
+                    const real g0v[3] = {ckcl, fac * cicj * inv_aij * inv_akl * sinv, wt};
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) {
+                        const real c0 = rijv[ax] * aj_aij - rt_aij * rpqv[ax];
+                        const real cp = rklv[ax] * al_akl + rt_akl * rpqv[ax];
+                        real tt[LIJ + 1][LKL + 1];
+                        tt[0][0] = g0v[ax];
+                        if (LIJ > 0) {
+                            tt[1][0] = c0 * g0v[ax];
+#pragma unroll
+                            for (int q = 1; q < LIJ; q++) tt[q + 1][0] = c0 * tt[q][0] + q * b10 * tt[q - 1][0];
+                        }
+#pragma unroll
+                        for (int cc = 0; cc < LKL; cc++) {
+#pragma unroll
+                            for (int q = 0; q <= LIJ; q++) {
+                                real v = cp * tt[q][cc];
+                                if (cc > 0) v += cc * b01 * tt[q][cc - 1];
+                                if (q > 0) v += q * b00 * tt[q - 1][cc];
+                                tt[q][cc + 1] = v;
+                            }
+                        }
+                        real* __restrict__ dst = buf + trr_off(sa) + (r * 3 + ax) * NT2;
+#pragma unroll
+                        for (int q = 0; q <= LIJ; q++)
+#pragma unroll
+                            for (int cc = 0; cc <= LKL; cc++) dst[q * (LKL + 1) + cc] = tt[q][cc];
+                    }
+                }
+#else
 #if WSYNC
                 for (int job = lane; job < GW * 3 * NROOTS; job += 64) {
                     const int sl = job / (3 * NROOTS), rem = job - sl * (3 * NROOTS);
@@ -1209,12 +1382,13 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             tt[q][cc + 1] = v;
                         }
                     }
-                    real* __restrict__ dst = buf + (sa * NROOTS * 3 + r * 3 + ax) * NT2;
+                    real* __restrict__ dst = buf + trr_off(sa) + (r * 3 + ax) * NT2;
 #pragma unroll
                     for (int q = 0; q <= LIJ; q++)
 #pragma unroll
                         for (int cc = 0; cc <= LKL; cc++) dst[q * (LKL + 1) + cc] = tt[q][cc];
                 }
+#endif  // PAROOT
             };
 
 #pragma unroll
@@ -1280,8 +1454,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         STAMP(10);
                         // ---------------- phase B: row lanes: own bra slice, ket HRR, integral accumulation
                         if (on) {
-                            const real* __restrict__ myT = sT + (NBUF > 1 ? (item & 1) : 0) * (G * NROOTS * 3 * NT2) +
-                                                           slot * (NROOTS * 3 * NT2);
+                            const real* __restrict__ myT = sT + (NBUF > 1 ? (item & 1) : 0) * (G * TRR_SLOT) + trr_off(slot);
 #if UNROLL_B
 #pragma unroll
 #else
@@ -1388,6 +1561,33 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         keep_jl = b2 == b && d2 == d;
                     }
 #if CJR
+#if NDM > 1
+#pragma unroll 1
+                    for (int dmi = 0; dmi < NDM; dmi++) {
+#else
+                    {
+                    constexpr int dmi = 0;
+#endif
+                    // this density matrix's tiles (row-lane mode: one ket slot); the code below is written for one matrix
+                    const real* const sDij_v = sDij + dmi * (WJ * WI); const real* const sDkl_v = sDkl + dmi * (WL * WK);
+                    const real* const sDik_v = sDik + dmi * (WI * WK); const real* const sDil_v = sDil + dmi * (WI * WL);
+                    const real* const sDjk_v = sDjk + dmi * (WJ * WK); const real* const sDjl_v = sDjl + dmi * (WJ * WL);
+                    double* const sJij_v = sJij + dmi * (WJ * WI); double* const sJkl_v = sJkl + dmi * (WL * WK);
+                    double* const sKik_v = sKik + dmi * (WI * WK); double* const sKil_v = sKil + dmi * (WI * WL);
+                    double* const sKjk_v = sKjk + dmi * (WJ * WK); double* const sKjl_v = sKjl + dmi * (WJ * WL);
+                    {
+                    const real* const sDij = sDij_v; const real* const sDkl = sDkl_v; const real* const sDik = sDik_v;
+                    const real* const sDil = sDil_v; const real* const sDjk = sDjk_v; const real* const sDjl = sDjl_v;
+                    double* const sJij = sJij_v; double* const sJkl = sJkl_v; double* const sKik = sKik_v;
+                    double* const sKil = sKil_v; double* const sKjk = sKjk_v; double* const sKjl = sKjl_v;
+#if ORED
+#pragma unroll
+                    for (int e = 0; e < CW * NFL; e++) jkl_acc[e] = 0;
+#pragma unroll
+                    for (int n = 0; n < EJ * CW; n++) kjk_acc[n] = 0;
+#pragma unroll
+                    for (int n = 0; n < EJ * NFL; n++) kjl_acc[n] = 0;
+#endif
                     if (on) {
                         // lane = bra component ci, registers = (cj, k, l): J_ij, K_ik, K_il are complete in the lane
                         const int jA0 = b * NFJ;
@@ -1432,7 +1632,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #if DO_J
 #pragma unroll
                         for (int oj = 0; oj < NFJ; oj++) lds_add(&sJij[(jA0 + oj) * WI + iA], (double)s_ij[oj]);
-                        if (!keep_kl) {
+                        if (!ORED && !keep_kl) {
 #pragma unroll
                             for (int kk = 0; kk < CW; kk++)
 #pragma unroll
@@ -1447,7 +1647,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         for (int kk = 0; kk < CW; kk++) lds_add(&sKik[iA * WK + kb + kk], (double)s_ik[kk]);
 #pragma unroll
                         for (int cl = 0; cl < NFL; cl++) lds_add(&sKil[iA * WL + lbs + cl], (double)s_il[cl]);
-                        if (!keep_jk) {
+                        if (!ORED && !keep_jk) {
 #pragma unroll
                             for (int oj = 0; oj < NFJ; oj++)
 #pragma unroll
@@ -1456,7 +1656,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                     kjk_acc[oj * CW + kk] = 0;
                                 }
                         }
-                        if (!keep_jl) {
+                        if (!ORED && !keep_jl) {
 #pragma unroll
                             for (int oj = 0; oj < NFJ; oj++)
 #pragma unroll
@@ -1467,10 +1667,98 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         }
 #endif
                     }
+#if ORED
+                    // ---- owner reduction of the values summed over the lanes of a quartet (J_kl, K_jk, K_jl of this step).
+                    //      Scratch of this wave: red[row][lane] inside its own part of the TRR array (dead until the next
+                    //      phase A).  Row r of a pass is summed by NH owner lanes, each over the quartets qs = h, h + NH, ...
+                    {
+                        double* __restrict__ red = (double*)(sT + wave_u * WREG);
+                        const int ox = lane % RG, oh = lane / RG;
+                        const double* __restrict__ row = red + ox * RSTR + oh * T;
+#pragma unroll
+                        for (int ps = 0; ps < NPASS; ps++) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int r = 0; r < RG; r++) {
+                                const int e = ps * RG + r;                  // (compile-time)
+                                if (e < NPART)
+                                    red[r * RSTR + lane] = e < NE0 ? jkl_acc[e < NE0 ? e : 0]
+                                                         : e < NE0 + NE1 ? kjk_acc[(e >= NE0 && e < NE0 + NE1) ? e - NE0 : 0]
+                                                                         : kjl_acc[e >= NE0 + NE1 ? e - NE0 - NE1 : 0];
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const int e = ps * RG + ox;
+                            const bool own = oh < NH && e < NPART;
+                            int blk = 2, off;
+                            {
+                                const int e1 = e - NE0, e2 = e - NE0 - NE1;
+                                off = (e2 / NFL) * WL + e2 % NFL;                                  // K_jl[oj][cl]
+                                if (e < NE0 + NE1) { blk = 1; off = (e1 / CW) * WK + CH * CW + e1 % CW; }     // K_jk[oj][kk]
+                                if (e < NE0) { blk = 0; off = (e % NFL) * WK + CH * CW + e / NFL; }           // J_kl[cl][kk]  (e = kk * NFL + cl)
+                            }
+#pragma unroll
+                            for (int k = 0; k < (GW + NH - 1) / NH; k++) {
+                                const int qs = oh + k * NH;
+                                const int qo = (wave * GW + qs) * per + step;
+                                if (own && qs < GW && qo < nact) {
+                                    double v[T];
+#pragma unroll
+                                    for (int u = 0; u < T; u++) v[u] = row[k * NH * T + u];
+                                    const int qd2 = s_act[qo];
+                                    const int a2 = qd2 % TSI, b2 = (qd2 / TSI) % TSJ, d2 = (qd2 / (TSI * TSJ)) % TSL;
+                                    const int c2 = QC(qd2 / (TSI * TSJ * TSL), a2, b2, d2);
+                                    double* dst = blk == 0 ? sJkl + (d2 * NFL) * WK + c2 * NFK + off
+                                                : blk == 1 ? sKjk + (b2 * NFJ) * WK + c2 * NFK + off
+                                                           : sKjl + (b2 * NFJ) * WL + d2 * NFL + off;
+                                    double sum = 0;
+#pragma unroll
+                                    for (int u = 0; u < T; u++) sum += v[u];
+                                    lds_add(dst, sum);
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+#if !WSYNC
+                    __syncthreads();          // the next phase A overwrites the scratch (it aliases the TRR array)
+#endif
+#endif
+                    }
+                    }
                 }
             }
 #else
+#if NDM > 1
+#pragma unroll 1
+                    for (int dmi = 0; dmi < NDM; dmi++) {
+#else
+                    {
+                    constexpr int dmi = 0;
+#endif
+                    // this density matrix's tiles (row-lane mode: one ket slot); the code below is written for one matrix
+                    const real* const sDij_v = sDij + dmi * (WJ * WI); const real* const sDkl_v = sDkl + dmi * (WL * WK);
+                    const real* const sDik_v = sDik + dmi * (WI * WK); const real* const sDil_v = sDil + dmi * (WI * WL);
+                    const real* const sDjk_v = sDjk + dmi * (WJ * WK); const real* const sDjl_v = sDjl + dmi * (WJ * WL);
+                    double* const sJij_v = sJij + dmi * (WJ * WI); double* const sJkl_v = sJkl + dmi * (WL * WK);
+                    double* const sKik_v = sKik + dmi * (WI * WK); double* const sKil_v = sKil + dmi * (WI * WL);
+                    double* const sKjk_v = sKjk + dmi * (WJ * WK); double* const sKjl_v = sKjl + dmi * (WJ * WL);
+                    {
+                    const real* const sDij = sDij_v; const real* const sDkl = sDkl_v; const real* const sDik = sDik_v;
+                    const real* const sDil = sDil_v; const real* const sDjk = sDjk_v; const real* const sDjl = sDjl_v;
+                    double* const sJij = sJij_v; double* const sJkl = sJkl_v; double* const sKik = sKik_v;
+                    double* const sKil = sKil_v; double* const sKjk = sKjk_v; double* const sKjl = sKjl_v;
                     real s_ij = 0, s_ik[CW], kil[NFL];
+                    if (USE_ORED) {          // step-local sums; lanes without a quartet contribute zeros to the owner sums
+#pragma unroll
+                        for (int e = 0; e < CW * NFL; e++) jkl_acc[e] = 0;
+#pragma unroll
+                        for (int kk = 0; kk < CW; kk++) { kjk_acc[kk] = 0; s_ik[kk] = 0; }
+#pragma unroll
+                        for (int cl = 0; cl < NFL; cl++) { kjl_acc[cl] = 0; kil[cl] = 0; }
+                    }
                     if (on) {
 #if DO_J
                         {
@@ -1507,7 +1795,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         // ---- atomics of the step
 #if DO_J
                         lds_add(&sJij[jA * WI + iA], (double)s_ij);
-                        if (!keep_kl) {
+                        if (!USE_ORED && !keep_kl) {
 #pragma unroll
                             for (int kk = 0; kk < CW; kk++)
 #pragma unroll
@@ -1518,19 +1806,141 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         }
 #endif
 #if DO_K
+                        if (!USE_ORED) {
 #pragma unroll
-                        for (int kk = 0; kk < CW; kk++) lds_add(&sKik[iA * WK + kb + kk], (double)s_ik[kk]);
+                            for (int kk = 0; kk < CW; kk++) lds_add(&sKik[iA * WK + kb + kk], (double)s_ik[kk]);
 #pragma unroll
-                        for (int cl = 0; cl < NFL; cl++) lds_add(&sKil[iA * WL + lbs + cl], (double)kil[cl]);
-                        if (!keep_jk) {
+                            for (int cl = 0; cl < NFL; cl++) lds_add(&sKil[iA * WL + lbs + cl], (double)kil[cl]);
+                            if (!keep_jk) {
 #pragma unroll
-                            for (int kk = 0; kk < CW; kk++) { lds_add(&sKjk[jA * WK + kb + kk], kjk_acc[kk]); kjk_acc[kk] = 0; }
-                        }
-                        if (!keep_jl) {
+                                for (int kk = 0; kk < CW; kk++) { lds_add(&sKjk[jA * WK + kb + kk], kjk_acc[kk]); kjk_acc[kk] = 0; }
+                            }
+                            if (!keep_jl) {
 #pragma unroll
-                            for (int cl = 0; cl < NFL; cl++) { lds_add(&sKjl[jA * WL + lbs + cl], kjl_acc[cl]); kjl_acc[cl] = 0; }
+                                for (int cl = 0; cl < NFL; cl++) { lds_add(&sKjl[jA * WL + lbs + cl], kjl_acc[cl]); kjl_acc[cl] = 0; }
+                            }
                         }
 #endif
+                    }
+                    if (USE_ORED) {
+                        // ---- owner reduction, lane = (ci, cj) form: every output but J_ij is a sum over lanes of the quartet --
+                        //      J_kl over all T lanes (type A), K_jk / K_jl over the NFI lanes of one cj (type B), K_ik / K_il over the
+                        //      NFJ lanes of one ci (type C).  Same scratch as above: red[row][lane] of this wave.
+                        constexpr int rg = RG > 0 ? RG : 1;
+                        constexpr int OB = NE0, OC = NE0 + NE1 + NE2;
+                        double* __restrict__ red = (double*)(sT + wave_u * WREG);
+#pragma unroll
+                        for (int ps = 0; ps < NPASS; ps++) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int r = 0; r < rg; r++) {
+                                const int e = ps * rg + r;                  // (compile-time)
+                                if (e < NPART) {
+                                    double val;
+                                    if (e < OB) val = jkl_acc[e < OB ? e : 0];
+                                    else if (e < OB + NE1) val = kjk_acc[(e >= OB && e < OB + NE1) ? e - OB : 0];
+                                    else if (e < OC) val = kjl_acc[(e >= OB + NE1 && e < OC) ? e - OB - NE1 : 0];
+                                    else if (e < OC + NE3) val = (double)s_ik[(e >= OC && e < OC + NE3) ? e - OC : 0];
+                                    else val = (double)kil[e >= OC + NE3 ? e - OC - NE3 : 0];
+                                    red[r * RSTR + lane] = val;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const int p_lo = ps * rg, p_hi = (ps * rg + rg < NPART) ? ps * rg + rg : NPART;
+                            // ---- type A rows of this pass: J_kl
+                            {
+                                const int lo = p_lo, hi = p_hi < OB ? p_hi : OB, n = hi - lo;
+                                if (n > 0) {
+                                    const int nd = n > 0 ? n : 1;
+#pragma unroll
+                                    for (int k = 0; k < (nd * GW + 63) / 64; k++) {
+                                        const int task = lane + 64 * k, rr = task % nd, qs = task / nd;
+                                        const int qo = (wave * GW + qs) * per + step;
+                                        if (task < n * GW && qo < nact) {
+                                            const double* __restrict__ src = red + (lo + rr - p_lo) * RSTR + qs * T;
+                                            double v[T];
+#pragma unroll
+                                            for (int u = 0; u < T; u++) v[u] = src[u];
+                                            const int qd2 = s_act[qo];
+                                            const int a2 = qd2 % TSI, b2 = (qd2 / TSI) % TSJ, d2 = (qd2 / (TSI * TSJ)) % TSL;
+                                            const int c2 = QC(qd2 / (TSI * TSJ * TSL), a2, b2, d2);
+                                            const int e = lo + rr;
+                                            double sum = 0;
+#pragma unroll
+                                            for (int u = 0; u < T; u++) sum += v[u];
+                                            lds_add(sJkl + (d2 * NFL + e % NFL) * WK + c2 * NFK + CH * CW + e / NFL, sum);
+                                        }
+                                    }
+                                }
+                            }
+                            // ---- type B rows: K_jk [CW], K_jl [NFL]; group = cj, members = the NFI lanes ci * NFJ + cj
+                            {
+                                const int lo = p_lo > OB ? p_lo : OB, hi = p_hi < OC ? p_hi : OC, n = hi - lo;
+                                if (n > 0) {
+                                    const int nd = n > 0 ? n : 1;
+#pragma unroll
+                                    for (int k = 0; k < (nd * GW * NFJ + 63) / 64; k++) {
+                                        const int task = lane + 64 * k, rr = task % nd, rest = task / nd;
+                                        const int grp = rest % NFJ, qs = rest / NFJ;
+                                        const int qo = (wave * GW + qs) * per + step;
+                                        if (task < n * GW * NFJ && qo < nact) {
+                                            const double* __restrict__ src = red + (lo + rr - p_lo) * RSTR + qs * T + grp;
+                                            double v[NFI];
+#pragma unroll
+                                            for (int u = 0; u < NFI; u++) v[u] = src[u * NFJ];
+                                            const int qd2 = s_act[qo];
+                                            const int a2 = qd2 % TSI, b2 = (qd2 / TSI) % TSJ, d2 = (qd2 / (TSI * TSJ)) % TSL;
+                                            const int c2 = QC(qd2 / (TSI * TSJ * TSL), a2, b2, d2);
+                                            const int eb = lo + rr - OB;
+                                            double sum = 0;
+#pragma unroll
+                                            for (int u = 0; u < NFI; u++) sum += v[u];
+                                            double* dst = eb < NE1 ? sKjk + (b2 * NFJ + grp) * WK + c2 * NFK + CH * CW + eb
+                                                                   : sKjl + (b2 * NFJ + grp) * WL + d2 * NFL + (eb - NE1);
+                                            lds_add(dst, sum);
+                                        }
+                                    }
+                                }
+                            }
+                            // ---- type C rows: K_ik [CW], K_il [NFL]; group = ci, members = the NFJ lanes ci * NFJ + cj
+                            {
+                                const int lo = p_lo > OC ? p_lo : OC, hi = p_hi, n = hi - lo;
+                                if (n > 0) {
+                                    const int nd = n > 0 ? n : 1;
+#pragma unroll
+                                    for (int k = 0; k < (nd * GW * NFI + 63) / 64; k++) {
+                                        const int task = lane + 64 * k, rr = task % nd, rest = task / nd;
+                                        const int grp = rest % NFI, qs = rest / NFI;
+                                        const int qo = (wave * GW + qs) * per + step;
+                                        if (task < n * GW * NFI && qo < nact) {
+                                            const double* __restrict__ src = red + (lo + rr - p_lo) * RSTR + qs * T + grp * NFJ;
+                                            double v[NFJ];
+#pragma unroll
+                                            for (int u = 0; u < NFJ; u++) v[u] = src[u];
+                                            const int qd2 = s_act[qo];
+                                            const int a2 = qd2 % TSI, b2 = (qd2 / TSI) % TSJ, d2 = (qd2 / (TSI * TSJ)) % TSL;
+                                            const int c2 = QC(qd2 / (TSI * TSJ * TSL), a2, b2, d2);
+                                            const int ec = lo + rr - OC;
+                                            double sum = 0;
+#pragma unroll
+                                            for (int u = 0; u < NFJ; u++) sum += v[u];
+                                            double* dst = ec < NE3 ? sKik + (a2 * NFI + grp) * WK + c2 * NFK + CH * CW + ec
+                                                                   : sKil + (a2 * NFI + grp) * WL + d2 * NFL + (ec - NE3);
+                                            lds_add(dst, sum);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#if !WSYNC
+                        __syncthreads();          // the next phase A overwrites the scratch (it aliases the TRR array)
+#endif
+                    }
+                    }
                     }
                 }
             }
@@ -1592,20 +2002,29 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
             }
 #else
+#if KARG_RELOAD
+            const int ndm_here = kf->n_dm - idm;
+#else
+            const int ndm_here = n_dm - idm;
+#endif
+#pragma unroll
+            for (int dmi = 0; dmi < NDM; dmi++) {
+            if (dmi >= ndm_here) break;
 #pragma unroll
             for (int ks = 0; ks < NKS; ks++) {
                 if (!kval[ks]) continue;
                 const int k0 = k0s[ks], l0 = l0s[ks];
 #if DO_J
-                flush_tile(sJkl + ks * (WL * WK), vj + idm * nao2, nao, l0, k0, WL, WK, tid);
+                flush_tile(sJkl + (dmi * NKS + ks) * (WL * WK), vj + (idm + dmi) * nao2, nao, l0, k0, WL, WK, tid);
 #endif
 #if DO_K
-                double* __restrict__ K = vk + idm * nao2;
-                flush_tile(sKik + ks * (WI * WK), K, nao, i0, k0, WI, WK, tid);
-                flush_tile(sKil + ks * (WI * WL), K, nao, i0, l0, WI, WL, tid);
-                flush_tile(sKjk + ks * (WJ * WK), K, nao, j0, k0, WJ, WK, tid);
-                flush_tile(sKjl + ks * (WJ * WL), K, nao, j0, l0, WJ, WL, tid);
+                double* __restrict__ K = vk + (idm + dmi) * nao2;
+                flush_tile(sKik + (dmi * NKS + ks) * (WI * WK), K, nao, i0, k0, WI, WK, tid);
+                flush_tile(sKil + (dmi * NKS + ks) * (WI * WL), K, nao, i0, l0, WI, WL, tid);
+                flush_tile(sKjk + (dmi * NKS + ks) * (WJ * WK), K, nao, j0, k0, WJ, WK, tid);
+                flush_tile(sKjl + (dmi * NKS + ks) * (WJ * WL), K, nao, j0, l0, WJ, WL, tid);
 #endif
+            }
             }
 #endif
             }
@@ -1622,8 +2041,14 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             double* __restrict__ vj = kf->vj;
 #endif
             // J_ij: summed over the whole ket chunk (lane-per-quartet mode: JREP replicas)
-            for (int rep = 0; rep < (TILE_1Q ? JREP : 1); rep++)
-                flush_tile(sJij + rep * (WJ * WI), vj + idm * nao2, nao, j0, i0, WJ, WI, tid);
+#if KARG_RELOAD
+            const int ndm_here = kf->n_dm - idm;
+#else
+            const int ndm_here = n_dm - idm;
+#endif
+            for (int dmi = 0; dmi < NDM && dmi < ndm_here; dmi++)
+                for (int rep = 0; rep < (TILE_1Q ? JREP : 1); rep++)
+                    flush_tile(sJij + (dmi * (TILE_1Q ? JREP : 1) + rep) * (WJ * WI), vj + (idm + dmi) * nao2, nao, j0, i0, WJ, WI, tid);
         }
 #endif
         STAMP(9);

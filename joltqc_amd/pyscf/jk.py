@@ -341,6 +341,7 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
                         rows.append((tt.offset[gi, gj] + s0, n_ij, tt.offset[gk, gl], n_kl,
                                      (int(gkey[gi, 1]), int(gkey[gj, 1]), int(gkey[gk, 1]), int(gkey[gl, 1]))))
     if world > 1:
+        build_tile_plan.last_predicted_load = _shard_assign(per_class, world)[1]     # ns per rank (diagnostics, tests)
         per_class = _shard_rows(per_class, rank, world)
     plans = {}
     for ang, rows in per_class.items():
@@ -377,39 +378,52 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
     return plans
 
 
-def _shard_rows(per_class, rank, world):
-    """This rank's share of the task rows.  Every rank evaluates the same deterministic assignment: classes are taken
-    in order of decreasing cost (tile-pair products x model FLOP per quartet); a class worth more than half a rank's
-    fair share is dealt row by row (strips of the Schwarz-sorted bra list) round-robin over the ranks, a cheaper class
-    goes as a whole to the least loaded rank -- so a small molecule does not pay every class's launch on every rank."""
+def _shard_assign(per_class, world):
+    """Deterministic assignment of the task rows to ``world`` ranks: {class: [rank of every row]} and the predicted load
+    (ns) of every rank.  Classes are taken in order of decreasing cost (tile-pair products x measured ns per quartet of
+    the class, gfx950_scheme.json; the FLOP model where unmeasured).  A class worth more than half a rank's fair share is
+    dealt ROW BY ROW (strips of the Schwarz-sorted bra list), each row -- heaviest first -- to the least loaded rank
+    (longest-processing-time rule: the rows of one class differ a lot in cost, the leading strips see the longest ket
+    lists, so a round-robin deal hands rank 0 the heaviest row of every group); a cheaper class goes as a whole to the
+    least loaded rank, so a small molecule does not pay every class's launch on every rank."""
     from ..roofline import quartet_flops
     measured = _router.class_cost_table()          # ns per quartet of the class on gfx950, where measured
     unit = {a: measured.get(_router.class_key(a), 1.5e-4 * float(quartet_flops(a))) for a in per_class}
     cost = {a: sum(r[1] * r[3] for r in rows) * unit[a] for a, rows in per_class.items()}
     fair = sum(cost.values()) / world
     load = [0.0] * world
-    mine = {}
-    start = 0
+    owner = {}
     for a in sorted(per_class, key=lambda a: (-cost[a], a)):
         rows = per_class[a]
         if cost[a] > 0.5 * fair and len(rows) >= world:
-            w = [r[1] * r[3] for r in rows]
-            for n, r in enumerate(rows):
-                tgt = (n + start) % world
-                load[tgt] += w[n] * unit[a]
-                if tgt == rank:
-                    mine.setdefault(a, []).append(r)
-            start += len(rows) % world
+            w = [r[1] * r[3] * unit[a] for r in rows]
+            own = [0] * len(rows)
+            for n in sorted(range(len(rows)), key=lambda n: (-w[n], n)):
+                tgt = min(range(world), key=lambda k: (load[k], k))
+                load[tgt] += w[n]
+                own[n] = tgt
+            owner[a] = own
         else:
             tgt = min(range(world), key=lambda k: (load[k], k))
             load[tgt] += cost[a]
-            if tgt == rank:
-                mine[a] = list(rows)
+            owner[a] = [tgt] * len(rows)
+    return owner, load
+
+
+def _shard_rows(per_class, rank, world):
+    """This rank's share of the task rows (every rank evaluates the same assignment, ``_shard_assign``)."""
+    owner, _ = _shard_assign(per_class, world)
+    mine = {}
+    for a, rows in per_class.items():
+        keep = [r for r, o in zip(rows, owner[a]) if o == rank]
+        if keep:
+            mine[a] = keep
     return mine
 
 
 _FIRST_USE_OK = set()       # kernel builds outside the verified manifest that passed their first-use cross-check (per process)
 
+NDM2 = __import__('os').environ.get('JQC_NDM2', '1') != '0'      # 0: one density matrix per integral evaluation (A/B, diagnostics)
 KCHUNK_MAX = int(__import__('os').environ.get('JQC_KCHUNK_MAX', '16'))
 SPLIT_BELOW_WGS = int(__import__('os').environ.get('JQC_SPLIT_BELOW', '1024'))
 NSPLIT_MAX = int(__import__('os').environ.get('JQC_NSPLIT_MAX', '8'))
@@ -619,6 +633,10 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     sid = side[n % len(side)]
                     sp = sid.cuda_stream
                     algo64 = _router.select_algo(ang, small=nblk < TARGET_WGS)
+                    if n_dm > 1 and NDM2 and _router.supports_ndm2(ang, algo64):
+                        # every pair of density matrices is contracted against ONE evaluation of the integrals
+                        # (reference jk/1q1t.cu:423-638); the kernel walks n_dm in pairs
+                        algo64 |= _router.VARIANT_NDM2
                     h64 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=algo64)
                     geo = (tabs_d.data_ptr() + row * 32, tab.shape[0], nblk, idx_p)
                     first_use_check(ang, algo64, False, h64, bucket)
@@ -636,6 +654,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     n_launch += 1
                     if split:
                         algo32 = _router.select_algo(ang, True)
+                        if n_dm > 1 and NDM2 and _router.supports_ndm2(ang, algo32):
+                            algo32 |= _router.VARIANT_NDM2
                         h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True, algo=algo32)
 
                         first_use_check(ang, algo32, True, h32, bucket)

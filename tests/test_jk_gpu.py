@@ -188,12 +188,17 @@ def test_ket_chunks_and_workgroup_splits(monkeypatch):
         assert n64 == len(dense.canonical_quartets(lay))
 
 
+ORED, PAROOT, NDM2 = 1 << 18, 1 << 19, 1 << 20        # include/jqc_hip.h (round 3: owner reduction, per-root phase A, two DMs)
+
+
 @pytest.mark.parametrize("variant", [0x21, 0x21 | 0x100, 0x21 | 0x400, 0x21 | 0x100 | 0x400, 0x22, 0x32, 0x21 | 0x800,
-                                     0x21 | 0x100 | 0x800, 0x1022, 0x2022, 0x3022])
+                                     0x21 | 0x100 | 0x800, 0x1022, 0x2022, 0x3022,
+                                     0x921 | ORED, 0x921 | ORED | PAROOT, 0xd21 | ORED | PAROOT, 0x521 | ORED, 0x421 | ORED | PAROOT,
+                                     0x30521 | ORED, 0x21 | ORED, 0x10d21 | ORED | PAROOT])
 def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
     """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
-    L2 | single TRR buffer | wave-local steps | j in registers | 2, 4, 8 ket pairs per iteration; include/jqc_hip.h
-    JQC_VARIANT_*): each must give the same J and K.
+    L2 | single TRR buffer | wave-local steps | j in registers | 2, 4, 8 ket pairs per iteration | owner reduction | per-root
+    phase A | integral-chunk caps; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.
     Role of the reference's 1q1t == 1qnt cross-check (jqc/backend/data/generate_fragment.py:278-309)."""
     from joltqc_amd.backend import jk as router
     from oracle import dense
@@ -281,7 +286,7 @@ def test_two_ranks_share_the_quartets_and_allreduce_the_fock_matrix():
     assert min(res[0][3], res[1][3]) > 0.25 * n_all
 
 
-@pytest.mark.parametrize("mode", ["jk", "j", "k", "lr", "fp32", "k_lr", "fp32_lr", "jk_main", "k_lr_main"])
+@pytest.mark.parametrize("mode", ["jk", "j", "k", "lr", "fp32", "k_lr", "fp32_lr", "jk_main", "k_lr_main", "jk_2dm", "jk_2dm_main"])
 def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     """All 140 angular classes s..g, CLASS BY CLASS: the kernel the scheme table selects for the class vs the CPU oracle
     restricted to the quartets of that class (three atoms, artificial s/p/d/f/g basis, the reference autotuner's kind of
@@ -303,6 +308,10 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     if main:
         monkeypatch.setattr(jkmod, "TARGET_WGS", 1)        # no launch counts as small; ket chunks up to KCHUNK_MAX
         mode = mode[:-5]
+    two_dm = mode == "jk_2dm"          # two density matrices in one call: the NDM = 2 builds (both contracted against ONE
+    if two_dm:                         # evaluation of the integrals, reference jk/1q1t.cu:423-638)
+        mode = "jk"
+        dm = np.stack([dm, _dm(mol.nao)[::-1, ::-1].copy() * 0.5 + 0.1 * np.eye(mol.nao)])
     with_j, with_k = mode not in ("k", "k_lr"), mode != "j"
     omega = 0.3 if mode.endswith("lr") else None
     cut64, tol = (1e100, 2e-5) if mode.startswith("fp32") else (1e-13, 1e-11)      # fp32: every quartet through the fp32 kernels
@@ -326,6 +335,10 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
                         n64, n32, _ = get_jk.quartet_counts()
                         if not err < tol or n64 + n32 != int(sel.sum()):
                             bad.append((key, err, n64 + n32, int(sel.sum())))
+                        if two_dm:          # the second matrix must not be a copy of the first one's result
+                            e2 = np.abs(_np(vk)[1] - rk[1]).max() / max(np.abs(rk[1]).max(), 1e-300)
+                            if not e2 < tol:
+                                bad.append((key, "dm2", e2))
     finally:
         os.environ.pop("JQC_ONLY_CLASS", None)
     assert nclass == 140 and not bad, bad

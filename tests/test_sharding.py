@@ -139,3 +139,40 @@ def test_launches_stay_below_the_work_item_limit(monkeypatch):
         kch = tab[:, 7] & 0xffff
         assert (kch == kch[0]).all() and kch[0] >= math.ceil(int((f[:, 1] * f[:, 3]).sum()) / 40)
         assert np.array_equal(tab[:, 4], -(-tab[:, 3] // kch)) and index[-1] == tab.shape[0] - 1
+
+
+@pytest.mark.parametrize("name,basis", [("0112-elongated-nitrogenous", "def2-tzvpp"), ("0425-globular-nitrogenous", "def2-svp")])
+def test_predicted_load_is_balanced_for_2_4_8_ranks(name, basis):
+    """BASELINE configs 4 / 5 sizes: the cost-aware deal of task rows (``_shard_assign``: measured ns per quartet of every
+    class x tile-pair products, heaviest row to the least loaded rank) leaves the predicted load of the slowest rank within
+    10 % of the mean for 2, 4 and 8 ranks, every row goes to exactly one rank, and every class has a weight (g classes included)."""
+    import math
+    from joltqc_amd.backend import jk as router
+    from joltqc_amd.constants import tile_width
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import jk as jkmod
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import jk as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mol = mole.Mole(atom=mole.read_xyz(os.path.join(root, "joltqc_amd/data/molecules", name + ".xyz")), basis=basis)
+    lay = BasisLayout.from_mol(mol, alignment=tile_width)
+    q = np.log(O.schwarz(lay.packed) + 1e-300).astype(np.float32)
+    q[lay.pad_id, :] = -100
+    q[:, lay.pad_id] = -100
+    tt = jkmod._TileTables(lay, 0.0, q_host=q)
+    log_cut, log_dm = math.log(1e-13), 0.0
+    full = jkmod.build_tile_plan(lay, tt, log_cut, log_dm, lambda a: True)
+    nrows = sum(p[0].shape[0] for p in full.values())
+    for world in (2, 4, 8):
+        parts = [jkmod.build_tile_plan(lay, tt, log_cut, log_dm, lambda a: True, shard=(r, world)) for r in range(world)]
+        load = jkmod.build_tile_plan.last_predicted_load
+        assert len(load) == world and max(load) < 1.10 * (sum(load) / world), (world, load)
+        assert sum(sum(p[0].shape[0] for p in part.values()) for part in parts) == nrows
+        # tile-pair products (~ quartets) per rank: no rank starves
+        work = [sum(int((p[0][:, 1].astype(np.int64) * p[0][:, 3]).sum()) for p in part.values()) for part in parts]
+        assert min(work) > 0.5 * sum(work) / world, (world, work)
+    cost = router.class_cost_table()
+    for a in full:
+        assert router.class_key(a) in cost, a
+    for l4 in [(4, 0, 0, 0), (4, 4, 4, 4), (4, 3, 2, 1)]:
+        assert router.class_key(l4) in cost, l4

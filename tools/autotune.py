@@ -27,6 +27,16 @@ CANDIDATES = [2 | MINW(1), 2 | MINW(2), 2 | MINW(3),
               1 | MINW(3) | RYS_L2 | WSYNC,
               1 | MINW(1) | CJR, 1 | MINW(1) | RYS_L2 | CJR, 1 | MINW(2) | RYS_L2 | CJR, 1 | MINW(2) | RYS_L2 | ST1 | CJR,
               1 | MINW(3) | RYS_L2 | ST1 | CJR]
+# round 3: owner reduction (ORED), per-root phase A (PAROOT) and integral-chunk caps for the row-lane forms.  JQC_TUNE_SET=ored:
+# the row-lane entries of the current table (baseline) + the new forms, for the classes of JQC_TUNE_CLASSES
+ORED, PAROOT = 1 << 18, 1 << 19
+ECAP = lambda code: code << 16
+ORED_SET = sorted({0x21, 0x121, 0x421, 0x521, 0x921, 0x10421, 0x10521, 0x10321, 0x10921} |
+                  {1 | MINW(2) | RYS_L2 | ORED | p | w | c | ECAP(e) for p in (0, PAROOT) for w in (0, WSYNC) for c in (0, CJR)
+                   for e in (0, 1, 3)} |
+                  {1 | MINW(2) | ORED | p | w | c for p in (0, PAROOT) for w in (0, WSYNC) for c in (0, CJR)})
+if os.environ.get("JQC_TUNE_SET") == "ored":
+    CANDIDATES = ORED_SET
 if os.environ.get("JQC_TUNE_ONLY"):
     CANDIDATES = [int(x, 0) for x in os.environ["JQC_TUNE_ONLY"].split(",")]
 MAX_1Q = 200
@@ -40,7 +50,12 @@ def nint(ang):
 
 
 def classes(lmax=3):
-    return [(a, b, c, d) for a in range(lmax + 1) for b in range(a + 1) for c in range(a + 1) for d in range(c + 1)]
+    allc = [(a, b, c, d) for a in range(lmax + 1) for b in range(a + 1) for c in range(a + 1) for d in range(c + 1)]
+    only = os.environ.get("JQC_TUNE_CLASSES")
+    if only and lmax == 3:
+        keep = {tuple(int(ch) for ch in k) for k in only.split(",")}
+        allc = [a for a in allc if a in keep]
+    return allc
 
 
 FP32 = int(os.environ.get("JQC_TUNE_FP32", "0"))     # 1: tune the fp32 kernels (every quartet through them)
