@@ -100,7 +100,8 @@ def purge_stale_cache():
     gtag = lib().jqc_grad_source_tag().decode()
     n = 0
     for f in os.listdir(KERNEL_CACHE):
-        if f.endswith(".hsaco") and not f.endswith("_" + tag + ".hsaco") and not f.endswith("_" + gtag + ".hsaco"):
+        stem = f[:-len(".scratch")] if f.endswith(".hsaco.scratch") else f       # (markers of pair kernels that would spill)
+        if stem.endswith(".hsaco") and not stem.endswith("_" + tag + ".hsaco") and not stem.endswith("_" + gtag + ".hsaco"):
             os.remove(os.path.join(KERNEL_CACHE, f))
             n += 1
     return n

@@ -1085,7 +1085,19 @@ int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, co
 {
     if (ngrids % NG || vvngrids % NG) return fail(-1, "VV10 grids must be padded to a multiple of %d", NG);
     if (ngrids == 0) return 0;
-    if (fp32)
+    // JQC_VV10_NOUT = 1: the one-point-per-lane form of rounds 1-2 (A/B); default: NOUT outer points per lane
+    static const int nout = getenv("JQC_VV10_NOUT") ? atoi(getenv("JQC_VV10_NOUT")) : 2;
+    const int nb = ngrids / NG;
+    if (fp32 && nout == 2)
+        hipLaunchKernelGGL((vv10_kernel_n<float, 2>), dim3((nb + 1) / 2), dim3(256), 0, (hipStream_t)stream, F_d, U_d, W_d,
+                           vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids);
+    else if (fp32 && nout == 4)
+        hipLaunchKernelGGL((vv10_kernel_n<float, 4>), dim3((nb + 3) / 4), dim3(256), 0, (hipStream_t)stream, F_d, U_d, W_d,
+                           vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids);
+    else if (!fp32 && nout >= 2)
+        hipLaunchKernelGGL((vv10_kernel_n<double, 2>), dim3((nb + 1) / 2), dim3(256), 0, (hipStream_t)stream, F_d, U_d, W_d,
+                           vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids);
+    else if (fp32)
         hipLaunchKernelGGL(vv10_kernel<float>, dim3(ngrids / NG), dim3(256), 0, (hipStream_t)stream, F_d, U_d, W_d,
                            vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids);
     else

@@ -35,6 +35,8 @@ TARGET_WGS = 2048        # a launch is split over the ket list until it has abou
 PAIR_MAX_L = 3           # highest angular momentum with ahead-of-time pair kernels (__graft_entry__._compile_pair)
 
 
+_PAIR_CHECKED = set()      # (source tag, long-range, pair classes) whose first-use cross-check passed in this process
+
 def generate_get_j(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, pair_wide_vk=PAIR_WIDE_VK):
     kern = generate_jk_kernel(basis_layout, cutoff_fp64=cutoff_fp64, cutoff_fp32=cutoff_fp32, pair_wide_vk=pair_wide_vk)
 
@@ -205,14 +207,15 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, pair_
             state["stats"].update(pair_launches=n_launch, pair_counter=counter, pair_classes=len(on_pairs), tile_classes=len(on_tiles))
             # first J of this closure (per range-separation mode): cross-check the pair kernels against the tiled J kernels
             # on this call's own density, as jk.first_use_check does for tile builds outside the verified manifest
-            if lr not in state["checked"] and os.environ.get("JQC_TRUST_KERNELS") != "1":
+            ckey = (_lib.lib().jqc_source_tag(), bool(lr), frozenset(on_pairs))
+            if ckey not in _PAIR_CHECKED and os.environ.get("JQC_TRUST_KERNELS") != "1":
                 ref = tile_jk(mol_ref, dm_t, hermi, vhfopt, True, False, omega, verbose)[0]
                 scale = float(ref.abs().max().item())
                 err = float((vj - ref).abs().max().item())
                 if not err <= 1e-9 * max(scale, 1e-300):
                     raise RuntimeError(f"pair-based J disagrees with the tiled J kernels on its first use (max |diff| {err:.3e}, "
                                        f"largest element {scale:.3e}): the pair kernels are rejected")
-            state["checked"].add(lr)
+            _PAIR_CHECKED.add(ckey)       # per process, like jk._FIRST_USE_OK: a scan / optimisation re-applies per geometry
         if isinstance(dm_in, np.ndarray) and getattr(get_jk, "return_numpy", False):
             vj = vj.cpu().numpy() if with_j else 0
             vk = vk.cpu().numpy() if with_k else 0

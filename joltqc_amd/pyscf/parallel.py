@@ -109,6 +109,8 @@ def drive_grid(fn, op, which=0):
         import torch
         m = mat if torch.is_tensor(mat) else np.asarray(mat)
         shape = tuple(m.shape)
+        if len(shape) not in (1, 2):      # checked BEFORE anything is announced: a shape the workers cannot rebuild would
+            raise ValueError(f"rho_fun / vxc_fun take one matrix [n0, n1] or one vector [n1], got shape {shape}")   # desynchronise the ranks
         _bcast_header([op, len(shape), shape[0], shape[-1], XC[xctype.upper()], which])
         return fn(mol, grids, xctype, _bcast_matrix(m, shape))
     if hasattr(fn, "stats"):
@@ -130,6 +132,23 @@ def stop():
         _bcast_header([OP_STOP])
 
 
+class driving:
+    """``with parallel.driving(): mf.kernel()`` on rank 0: the workers are released from ``serve()`` whatever happens inside
+    the block (an exception between a call's announcement and its all-reduce still leaves them inside that collective: give
+    the process group a timeout, ``init_process_group(..., timeout=...)``, so that they fail instead of waiting forever)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            stop()
+        except Exception:            # noqa: BLE001  (the group may already be broken: do not mask the original error)
+            if exc_type is None:
+                raise
+        return False
+
+
 def serve(handlers):
     """Ranks > 0: mirror rank 0's calls until ``stop()``.  ``handlers`` = {OP_JK: sharded get_jk, OP_RHO / OP_VXC: {grid
     index: (rho_fun / vxc_fun, mol, grids or a callable returning them)}, OP_VV10: vv10_sums} or a patched mean-field
@@ -144,6 +163,8 @@ def serve(handlers):
         if op == OP_STOP:
             return ncalls
         ncalls += 1
+        if op in (OP_RHO, OP_VXC):
+            assert int(h[1]) in (1, 2), f"grid call announced with a {int(h[1])}-dimensional argument"
         if op == OP_JK:
             ndim, n_dm, nao = int(h[1]), int(h[2]), int(h[3])
             shape = (n_dm, nao, nao) if ndim == 3 else (nao, nao)

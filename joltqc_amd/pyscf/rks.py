@@ -276,7 +276,7 @@ def generate_rks_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shar
     def _eval_xc(ni, xc_code, rho, xctype, dev):
         """``ni.eval_xc_eff`` (libxc, third party) on the caller's side of the boundary: a plain PySCF NumInt takes and
         returns NumPy arrays, a device-resident one (GPU4PySCF-like, ``_jqc_numpy_boundary`` False) device arrays."""
-        if getattr(ni, "_jqc_numpy_boundary", True):
+        if getattr(ni, "_jqc_numpy_boundary", False):      # (unmarked NumInt: device-side, like the reference's generate_* closures)
             exc, vxc = ni.eval_xc_eff(xc_code, rho.cpu().numpy(), deriv=1, xctype=xctype)[:2]
         else:
             exc, vxc = ni.eval_xc_eff(xc_code, rho, deriv=1, xctype=xctype)[:2]

