@@ -192,6 +192,39 @@ def grid_leg(mol, nsteps=5):
         out[label] = {"ms": dt * 1e3, "points_x_ao_pairs_per_s": pairs / dt, "tflops": fl / dt / 1e12,
                       "frac_fp64_mfma_peak": fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS, "mean_ao_per_block": float(m.mean()),
                       "ms_each_step": [round(x * 1e3, 3) for x in each]}
+    # meta-GGA (ndim 5: the tau GEMMs; BASELINE config 4's functional is one): flops = 256 (8 m^2 + 10 m) rho, 256 (8 m^2 + ...) vxc
+    wv5 = torch.rand((5, n), dtype=torch.float64, device="cuda")
+    mg = {}
+    for fn, arg, label in ((rho_k, dm, "rho"), (vxc_k, wv5, "vxc")):
+        fn(mol, g, "MGGA", arg); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(nsteps):
+            fn(mol, g, "MGGA", arg)
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t) / nsteps
+        m = rho_k.stats["nrow_h"].astype(float)
+        flm = 4.0 * 2.0 * float((m * m).sum()) * 256 + 10.0 * 256 * float(m.sum())       # four GEMMs (phi, d_x, d_y, d_z) + dots
+        mg[label] = {"ms": dtm * 1e3, "tflops": flm / dtm / 1e12, "frac_fp64_mfma_peak": flm / dtm / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+    out["meta_gga"] = mg
+    # VV10 pair sums (reference dft/vv10.cu): 262 144 points of this grid against themselves, FP32 inner loop / FP64 accumulation,
+    # 30 flop per pair against the FP32 vector peak
+    try:
+        from joltqc_amd.roofline import FP32_VALU_PEAK_TFLOPS
+    except ImportError:
+        FP32_VALU_PEAK_TFLOPS = 157.3
+    nv = min(262144, n)
+    xyz = torch.from_numpy(np.ascontiguousarray(coords[:nv].T)).cuda()
+    rnd = torch.rand((3, nv), dtype=torch.float64, device="cuda")
+    outer = torch.cat([xyz, rnd[0:1] + 0.5, rnd[1:2] + 0.5]).contiguous()
+    inner = torch.cat([xyz, rnd[0:1] + 0.5, rnd[1:2] + 0.5, rnd[2:3] * 1e-3]).contiguous()
+    rks.vv10_sums(outer, inner, True); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3):
+        rks.vv10_sums(outer, inner, True)
+    torch.cuda.synchronize()
+    dtv = (time.perf_counter() - t) / 3
+    out["vv10"] = {"points": nv, "ms": dtv * 1e3, "pairs_per_s": nv * nv / dtv, "tflops_30flop_per_pair": 30.0 * nv * nv / dtv / 1e12,
+                   "frac_fp32_valu_peak": 30.0 * nv * nv / dtv / 1e12 / FP32_VALU_PEAK_TFLOPS}
     # the same two calls with the default DFT cutoffs of apply() (cutoff_fp64 = 1e-6: weak AO pairs through the FP32 MFMA)
     _, rho_m, vxc_m = rks.generate_rks_kernel(lay, cutoff_fp64=1e-6, cutoff_fp32=1e-13)
     for fn, arg, label in ((rho_m, dm, "rho"), (vxc_m, wv, "vxc")):

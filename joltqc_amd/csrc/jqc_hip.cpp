@@ -1028,10 +1028,19 @@ int jqc_dft_rho(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int
 {
     if (nblk <= 0) return 0;
     if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
-    if (ndim > 4)
+    static const int mgga_one_launch = getenv("JQC_RHO_MGGA") ? atoi(getenv("JQC_RHO_MGGA")) : 0;      // 1: the <1,4> form of rounds 1-2
+    if (ndim > 4 && mgga_one_launch)
         hipLaunchKernelGGL((rho_mfma_kernel<1, 4>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
                            (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32, order_d);
-    else
+    else if (ndim > 4) {
+        // rho, grad rho from C = D phi; tau = 1/2 sum_x (D d_x phi) . d_x phi in two more launches (same stream: each adds to rho[4])
+        hipLaunchKernelGGL((rho_mfma_kernel<4, 1, 0>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32, order_d);
+        hipLaunchKernelGGL((rho_mfma_kernel<2, 2, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32, order_d);
+        hipLaunchKernelGGL((rho_mfma_kernel<4, 1, 3>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32, order_d);
+    } else
         hipLaunchKernelGGL((rho_mfma_kernel<4, 1>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
                            (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, dm_d, nao, ndim, rho_d, row_la_d, thr64, thr32, order_d);
     HIP_OK(hipGetLastError());
@@ -1086,7 +1095,8 @@ int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, co
     if (ngrids % NG || vvngrids % NG) return fail(-1, "VV10 grids must be padded to a multiple of %d", NG);
     if (ngrids == 0) return 0;
     // JQC_VV10_NOUT = 1: the one-point-per-lane form of rounds 1-2 (A/B); default: NOUT outer points per lane
-    static const int nout = getenv("JQC_VV10_NOUT") ? atoi(getenv("JQC_VV10_NOUT")) : 2;
+    // (measured, N = 262 144, FP32 inner loop: 1 point per lane 49.0 ms, 2: 46.7 ms, 4: 42.3 ms; profiles/r03_vv10_outer_points_per_lane_1_2_4.txt)
+    static const int nout = getenv("JQC_VV10_NOUT") ? atoi(getenv("JQC_VV10_NOUT")) : 4;
     const int nb = ngrids / NG;
     if (fp32 && nout == 2)
         hipLaunchKernelGGL((vv10_kernel_n<float, 2>), dim3((nb + 1) / 2), dim3(256), 0, (hipStream_t)stream, F_d, U_d, W_d,

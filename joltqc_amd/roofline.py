@@ -10,6 +10,7 @@ shell quartet of class ``(li,lj,lk,ll; npi,npj,npk,npl)``:
 
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X datasheet: 256 CU x 4 SIMD x 16 FP64 FMA lanes/clk x 2 flop x 2.4 GHz
 FP64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: the datasheet's FP64 matrix rate equals the vector rate
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBS = 8000.0
 
 

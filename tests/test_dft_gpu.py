@@ -136,6 +136,8 @@ def test_incremental_nr_rks_with_slater_exchange():
 
     from standin_scf import SlaterNumInt
     ni = SlaterNumInt()                       # NumPy-only, like libxc's NumInt: a device array handed to it raises
+    ni._jqc_numpy_boundary = True             # what apply() marks on a CPU object's NumInt; an unmarked one is served device arrays
+                                              # (the reference's generate_* closures stay device-side)
     np.random.seed(1)
     c = np.random.rand(mol.nao, 5) - 0.5
     dm1 = 2 * c @ c.T
