@@ -178,14 +178,16 @@ def grid_leg(mol, nsteps=5):
     wv = torch.rand((4, n), dtype=torch.float64, device="cuda")
     out = {"xc": "GGA", "ngrids": n, "nao": mol.nao, "grid": f"Becke, {per} points per atom (30 radial x 128 angular), box-sorted"}
     for fn, arg, label in ((rho_k, dm, "rho"), (vxc_k, wv, "vxc")):
-        fn(mol, g, "GGA", arg); torch.cuda.synchronize()
+        for _ in range(2):                                           # (the second call still pays one-off set-up: two warm-ups)
+            fn(mol, g, "GGA", arg)
+        torch.cuda.synchronize()
         each = []
         for _ in range(nsteps):
             t = time.perf_counter()
             fn(mol, g, "GGA", arg)
             torch.cuda.synchronize()
             each.append(time.perf_counter() - t)
-        dt = sum(each) / nsteps
+        dt = float(np.median(each))
         m = rho_k.stats["nrow_h"].astype(float)                      # significant Cartesian AOs per 256-point block
         pairs = float((m * m).sum()) * 256                            # grid points x AO pairs actually contracted
         fl = 2.0 * pairs + 8.0 * 256 * float(m.sum())                # 256 (2 m^2 + 8 m) per block

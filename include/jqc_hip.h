@@ -59,6 +59,8 @@ const char* jqc_version(void);
 const char* jqc_source_tag(void);
 /* the same for the gradient kernels (jk_grad.hip on top of the sources above) */
 const char* jqc_grad_source_tag(void);
+/* the same for the pair-based J kernels (pair_vj.hip) */
+const char* jqc_pair_source_tag(void);
 
 /* Runtime set-up.  src_dir holds the kernel sources (joltqc_amd/csrc/kernels), cache_dir receives
  * the gfx950 code objects (one .hsaco per class/variant; replaces CuPy's cubin cache, examples/04). */

@@ -74,6 +74,7 @@ def lib():
         L.jqc_gen_jk_grad_kernel.argtypes = [i32] * 6
         L.jqc_jk_grad_launch.argtypes = [i32, i32, vp, vp, i32, vp, vp, i32, i32, f64, f64, f64, vp, vp, i64, i32, vp]
         L.jqc_grad_source_tag.restype = c.c_char_p
+        L.jqc_pair_source_tag.restype = c.c_char_p
         L.jqc_pair_ket_density.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp, vp]
         L.jqc_pair_vj_launch.argtypes = [i32, i32, vp, vp, vp, f64, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, i32,
                                          i32, vp, vp]
@@ -98,10 +99,11 @@ def purge_stale_cache():
     """Remove cached code objects that were built from other versions of the kernel sources."""
     tag = lib().jqc_source_tag().decode()
     gtag = lib().jqc_grad_source_tag().decode()
+    ptag = lib().jqc_pair_source_tag().decode()
     n = 0
     for f in os.listdir(KERNEL_CACHE):
         stem = f[:-len(".scratch")] if f.endswith(".hsaco.scratch") else f       # (markers of pair kernels that would spill)
-        if stem.endswith(".hsaco") and not stem.endswith("_" + tag + ".hsaco") and not stem.endswith("_" + gtag + ".hsaco"):
+        if stem.endswith(".hsaco") and not any(stem.endswith("_" + t + ".hsaco") for t in (tag, gtag, ptag)):
             os.remove(os.path.join(KERNEL_CACHE, f))
             n += 1
     return n

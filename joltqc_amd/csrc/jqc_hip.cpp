@@ -32,6 +32,7 @@ std::mutex g_mu;
 std::string g_src_dir, g_cache_dir;
 int g_tsw[5] = {8, 4, 4, 2, 1};     // shells per tile edge by angular momentum (jqc_set_tile_widths)
 std::string g_src_tag = "nosrc";   // FNV-1a of every kernel source: stale code objects are never reused
+std::string g_pair_tag = "nosrc";  // pair-based J kernels (pair_vj.hip + common headers)
 std::string g_grad_tag = "nosrc";  // same for the gradient kernels (jk_grad.hip + the headers it includes), kept apart so that
                                    // work on them does not invalidate the verified J/K code objects
 
@@ -521,6 +522,7 @@ const char* jqc_last_error(void) { return g_err.c_str(); }
 const char* jqc_version(void) { return "joltqc_amd 0.1 (gfx950)"; }
 const char* jqc_source_tag(void) { return g_src_tag.c_str(); }
 const char* jqc_grad_source_tag(void) { return g_grad_tag.c_str(); }
+const char* jqc_pair_source_tag(void) { return g_pair_tag.c_str(); }
 
 int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
 {
@@ -528,15 +530,18 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
     g_src_dir = src_dir ? src_dir : "";
     g_cache_dir = cache_dir ? cache_dir : "";
     if (!g_cache_dir.empty()) mkdir(g_cache_dir.c_str(), 0755);
-    unsigned long long h = 1469598103934665603ull;
-    for (const char* f : {"jk_common.h", "jk_axis.h", "jk_1q1t.hip", "jk_tile.hip", "schwarz.hip", "pair_vj.hip"}) {
-        const std::string txt = read_file(g_src_dir + "/" + f);
+    // One tag per kernel family = FNV-1a of the family's own source + the shared headers + everything that decides the build
+    // (extra definitions, build policy of this file, hiprtc version and options): an edit of jk_tile.hip does not invalidate
+    // the pair-J or gradient code objects, and vice versa.  The verified-build manifest is keyed on the J/K tag.
+    auto mix = [](unsigned long long h, const std::string& txt) {
         for (unsigned char ch : txt) { h ^= ch; h *= 1099511628211ull; }
-    }
-    if (const char* extra = getenv("JQC_EXTRA_DEFS"))
-        for (const char* c = extra; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+        return h;
+    };
+    unsigned long long h0 = 1469598103934665603ull;
+    for (const char* f : {"jk_common.h", "jk_axis.h"}) h0 = mix(h0, read_file(g_src_dir + "/" + f));
+    if (const char* extra = getenv("JQC_EXTRA_DEFS")) h0 = mix(h0, extra);
     // (bump when the build logic of jqc_gen_jk_kernel changes: MINW rebuild loop, ECAP codes, KARG_RELOAD choice, variant bits)
-    for (const char* c = "build-policy-r3:karg-reload-iff-scratch,ored,paroot,ndm2"; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+    h0 = mix(h0, "build-policy-r3:karg-reload-iff-scratch,ored,paroot,ndm2,family-tags");
     // compiler version and option set: register allocation decides which builds pass the gates, so code
     // objects of another hiprtc are other builds -- not reused from the cache, not covered by the verified manifest
     {
@@ -544,19 +549,19 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
         (void)hiprtcVersion(&major, &minor);
         char ver[64];
         snprintf(ver, sizeof ver, "hiprtc-%d.%d", major, minor);
-        for (const char* c = ver; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
-        for (const char* o : kHiprtcOpts)
-            for (const char* c = o; *c; c++) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+        h0 = mix(h0, ver);
+        for (const char* o : kHiprtcOpts) h0 = mix(h0, o);
     }
-    char tag[32];
-    snprintf(tag, sizeof tag, "%010llx", h & 0xffffffffffull);
-    g_src_tag = tag;
-    {
-        const std::string txt = read_file(g_src_dir + "/jk_grad.hip");
-        for (unsigned char ch : txt) { h ^= ch; h *= 1099511628211ull; }
+    auto tag_of = [&](std::initializer_list<const char*> files) {
+        unsigned long long h = h0;
+        for (const char* f : files) h = mix(h, read_file(g_src_dir + "/" + f));
+        char tag[32];
         snprintf(tag, sizeof tag, "%010llx", h & 0xffffffffffull);
-        g_grad_tag = tag;
-    }
+        return std::string(tag);
+    };
+    g_src_tag = tag_of({"jk_1q1t.hip", "jk_tile.hip", "schwarz.hip"});
+    g_pair_tag = tag_of({"pair_vj.hip"});
+    g_grad_tag = tag_of({"jk_grad.hip"});
     return 0;
 }
 
@@ -769,7 +774,7 @@ int jqc_gen_pair_vj_kernel(int li, int lj, int lk, int ll, int rys_lr, int compi
     }
     char entry[64];
     snprintf(entry, sizeof entry, "pair_vj_%d%d%d%d", li, lj, lk, ll);
-    const std::string out = g_cache_dir + "/" + key + "_" + g_src_tag + ".hsaco";
+    const std::string out = g_cache_dir + "/" + key + "_" + g_pair_tag + ".hsaco";
     const std::string none = out + ".scratch";            // marker: the build spills, never load it
     Kernel k;
     k.key = key;

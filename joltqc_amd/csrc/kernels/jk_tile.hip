@@ -73,6 +73,12 @@ constexpr int NQ = TSI * TSJ * TSK * TSL;
 #else
 #define STAGE_ALL_ 0
 #endif
+#ifndef SKIP_EMPTY
+#define SKIP_EMPTY 1 // a ket tile pair whose smallest shell-pair index lies above the largest one of the bra tile pair holds no canonical
+                    // quartet ((ij) >= (kl), reference screen_jk_tasks.cu:202-239): it is neither staged nor screened.  In the classes
+                    // whose bra and ket lists coincide ((ps|ps), (dp|dp), ...) 44 % of the iterations are of that kind
+                    // (profiles/r02_survivor_statistics.txt).
+#endif
 #ifndef NDM
 #define NDM 1       // density matrices contracted against ONE evaluation of the integrals (1 or 2): the kernel walks the n_dm
                     // matrices of a call in groups of NDM; D and Fock tiles of a group live in LDS side by side.  Reference:
@@ -484,6 +490,10 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     const int cand_lo = NQ * sid / nsplit, cand_hi = NQ * (sid + 1) / nsplit;
     const int bij = lb / nchunk, ch = lb - bij * nchunk;
     const int kt0 = ch * kchunk, kt1 = min(nkl, kt0 + kchunk);
+    // (the host may round the chunk count of a task row up to a multiple of 8 and start every row at a multiple of 8, so that
+    //  workgroup b and ket chunk b mod 8 always meet on the same XCD -- blocks are dealt round-robin over the 8 XCDs -- and the
+    //  ket-side tables of a chunk stay in ONE L2: the surplus workgroups have nothing to do)
+    if (kt0 >= nkl || bij >= tk[1]) return;
     const unsigned pij = tpair_sh[ij0 + bij], aoij = tpair_ao[ij0 + bij];
     const float qij = tpair_q[ij0 + bij] + log_max_dm;
     if (qij + tpair_q[kl0 + kt0] <= cut_lo) return;          // ket list is sorted: nothing in this chunk survives
@@ -554,9 +564,11 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 
 #if KARG_RELOAD
     for (int idm = 0; idm < kargs()->n_dm; idm += NDM) {
+        const int ndm_grp = NDM > 1 ? kargs()->n_dm - idm : 1;      // density matrices of this group that exist
 #else
     for (int idm = 0; idm < n_dm; idm += NDM) {
         const real* __restrict__ D = dm + idm * nao2;
+        const int ndm_grp = NDM > 1 ? n_dm - idm : 1;
 #endif
 #if DO_J
         __syncthreads();
@@ -565,10 +577,8 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             const KArgs AS4* kd = kargs();
             const int nao = kd->nao;
             const real* __restrict__ D = kd->dm + idm * ((size_t)nao * nao);
-            const int ndm_here = kd->n_dm - idm;
-#else
-            const int ndm_here = n_dm - idm;
 #endif
+            const int ndm_here = ndm_grp;
             TileRegs<WJ, WI> r[NDM];
 #pragma unroll
             for (int dmi = 0; dmi < NDM; dmi++)       // (a group's missing matrix reads as zero: nao = 0 fails every bounds test)
@@ -604,6 +614,18 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 ksh0s[ks] = pkl >> 16; lsh0s[ks] = pkl & 0xffff;
                 k0s[ks] = aokl >> 16; l0s[ks] = aokl & 0xffff;
             }
+#if SKIP_EMPTY
+            {
+                const int bra_max = (ish0 + TSI - 1) * nbas + jsh0 + TSJ - 1;
+                bool any = false;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    kval[ks] = kval[ks] && ksh0s[ks] * nbas + lsh0s[ks] <= bra_max;
+                    any = any || kval[ks];
+                }
+                if (!any) continue;
+            }
+#endif
             parity ^= 1;
             // index arithmetic of the staging / flush loops is re-derived from an opaque copy of the thread id: keeps
             // the (cheap) loop-invariant addresses from being hoisted over the compute phase and spilled there
@@ -735,11 +757,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 const real* __restrict__ ppk = pair_tab + (size_t)tpair_pp[kl0 + kt + ks] * 27;
 #pragma unroll
                 for (int u = 0; u < NPK; u++) rpk[u] = tid + u * TBLOCK < TSK * TSL * 27 ? ppk[tid + u * TBLOCK] : real(0);
-#if KARG_RELOAD
-                const int ndm_here = ka->n_dm - idm;
-#else
-                const int ndm_here = n_dm - idm;
-#endif
+            const int ndm_here = ndm_grp;
 #if DO_J
                 TileRegs<WL, WK> rkl[NDM];
 #pragma unroll
@@ -824,7 +842,11 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             const int nact = __builtin_amdgcn_readfirstlane((int)s_nact[parity]);
             if (nact == 0) continue;
             const int npi = __builtin_amdgcn_readfirstlane((int)sBas[10]), npj = __builtin_amdgcn_readfirstlane((int)sBas[OFF_J + 10]);
-            const int npk = __builtin_amdgcn_readfirstlane((int)sBas[OFF_K + 10]), npl = __builtin_amdgcn_readfirstlane((int)sBas[OFF_L + 10]);
+            int kv0 = 0;                       // first staged ket slot (every slot of a task row has the same primitive counts)
+#pragma unroll
+            for (int ks = NKS - 1; ks >= 0; ks--)
+                if (kval[ks]) kv0 = ks;
+            const int npk = __builtin_amdgcn_readfirstlane((int)sBas[OFF_K + kv0 * KSTR + 10]), npl = __builtin_amdgcn_readfirstlane((int)sBas[OFF_L + kv0 * KSTR + 10]);
             if (idm == 0) nq_done += nact;
 
 #if TILE_1Q
@@ -941,7 +963,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 const int iA = a * NFI, jA = b * NFJ, kA = c * NFK, lA = d * NFL;
 #if NDM > 1
 #pragma unroll 1
-                for (int dmi = 0; dmi < NDM; dmi++) {
+                for (int dmi = 0; dmi < NDM && dmi < ndm_grp; dmi++) {
 #else
                 {
                 constexpr int dmi = 0;
@@ -1563,7 +1585,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #if CJR
 #if NDM > 1
 #pragma unroll 1
-                    for (int dmi = 0; dmi < NDM; dmi++) {
+                    for (int dmi = 0; dmi < NDM && dmi < ndm_grp; dmi++) {
 #else
                     {
                     constexpr int dmi = 0;
@@ -1733,7 +1755,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #else
 #if NDM > 1
 #pragma unroll 1
-                    for (int dmi = 0; dmi < NDM; dmi++) {
+                    for (int dmi = 0; dmi < NDM && dmi < ndm_grp; dmi++) {
 #else
                     {
                     constexpr int dmi = 0;
@@ -2002,11 +2024,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
             }
 #else
-#if KARG_RELOAD
-            const int ndm_here = kf->n_dm - idm;
-#else
-            const int ndm_here = n_dm - idm;
-#endif
+            const int ndm_here = ndm_grp;
 #pragma unroll
             for (int dmi = 0; dmi < NDM; dmi++) {
             if (dmi >= ndm_here) break;
@@ -2041,11 +2059,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             double* __restrict__ vj = kf->vj;
 #endif
             // J_ij: summed over the whole ket chunk (lane-per-quartet mode: JREP replicas)
-#if KARG_RELOAD
-            const int ndm_here = kf->n_dm - idm;
-#else
-            const int ndm_here = n_dm - idm;
-#endif
+            const int ndm_here = ndm_grp;
             for (int dmi = 0; dmi < NDM && dmi < ndm_here; dmi++)
                 for (int rep = 0; rep < (TILE_1Q ? JREP : 1); rep++)
                     flush_tile(sJij + (dmi * (TILE_1Q ? JREP : 1) + rep) * (WJ * WI), vj + (idm + dmi) * nao2, nao, j0, i0, WJ, WI, tid);

@@ -365,8 +365,14 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
             nsplit = int(max(1, min(NSPLIT_MAX, SPLIT_BELOW_WGS // max(nblk1, 1), nq // 16)))
         tab = np.zeros((len(rows), 8), dtype=np.int32)
         blk = 0
+        align = CHUNK_ALIGN if nsplit == 1 else 1
         for n, (ij0, nij, kl0, nkl, _) in enumerate(rows):
             nchunk = -(-nkl // kchunk)
+            if align > 1 and nchunk > align:
+                # XCD affinity: chunk count and first block of the row are multiples of 8 (the surplus workgroups return at once),
+                # so ket chunk c of EVERY bra pair runs on XCD (c mod 8) and its ket-side tables are shared through one L2
+                nchunk = -(-nchunk // align) * align
+                blk = -(-blk // align) * align
             tab[n] = (ij0, nij, kl0, nkl, nchunk, blk, 0, kchunk | (nsplit << 16))
             blk += nij * nchunk * nsplit
         if blk * 512 >= 2 ** 32:                 # (512: the widest workgroup of the tiled kernels)
@@ -424,6 +430,7 @@ def _shard_rows(per_class, rank, world):
 _FIRST_USE_OK = set()       # kernel builds outside the verified manifest that passed their first-use cross-check (per process)
 
 NDM2 = __import__('os').environ.get('JQC_NDM2', '1') != '0'      # 0: one density matrix per integral evaluation (A/B, diagnostics)
+CHUNK_ALIGN = int(__import__('os').environ.get('JQC_CHUNK_ALIGN', '1'))   # 8: ket chunk <-> XCD affinity (needs kernels with the surplus-workgroup guard)
 KCHUNK_MAX = int(__import__('os').environ.get('JQC_KCHUNK_MAX', '16'))
 SPLIT_BELOW_WGS = int(__import__('os').environ.get('JQC_SPLIT_BELOW', '1024'))
 NSPLIT_MAX = int(__import__('os').environ.get('JQC_NSPLIT_MAX', '8'))

@@ -207,7 +207,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, pair_
             state["stats"].update(pair_launches=n_launch, pair_counter=counter, pair_classes=len(on_pairs), tile_classes=len(on_tiles))
             # first J of this closure (per range-separation mode): cross-check the pair kernels against the tiled J kernels
             # on this call's own density, as jk.first_use_check does for tile builds outside the verified manifest
-            ckey = (_lib.lib().jqc_source_tag(), bool(lr), frozenset(on_pairs))
+            ckey = (_lib.lib().jqc_pair_source_tag(), _lib.lib().jqc_source_tag(), bool(lr), frozenset(on_pairs))
             if ckey not in _PAIR_CHECKED and os.environ.get("JQC_TRUST_KERNELS") != "1":
                 ref = tile_jk(mol_ref, dm_t, hermi, vhfopt, True, False, omega, verbose)[0]
                 scale = float(ref.abs().max().item())
