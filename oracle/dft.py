@@ -12,8 +12,10 @@ Follows (file:line under /root/reference):
 The dense formulas ARE the reference tests' oracle (they compare against ni.eval_ao + ni.eval_rho and
 ao.dot((w ao).T)).  PINNED (tests/test_dft_known_answers.py): an RKS SCF built from this module, oracle/xc.py and
 oracle/rks.py reproduces the energies the reference's own tests hold for H2O / def2-TZVPP
-(jqc/pyscf/tests/test_dft.py:75-86): "LDA,vwn5" -75.9046410402 to 1e-9 Eh, "PBE" -76.3800182418 to 6e-8 Eh (LDA and GGA
-branches: AO values, gradients, the V_xc conventions).  The AO values are also checked against analytic normalisation
+(jqc/pyscf/tests/test_dft.py:75-114): "LDA,vwn5" -75.9046410402 to 1e-9 Eh, "PBE" -76.3800182418 to 6e-8 Eh, "B3LYP"
+-76.4666495594 (spherical) to 3e-9 Eh and -76.4672144985 (Cartesian), "HYB_GGA_XC_WB97" -76.4486274326 to 6e-8 Eh (LDA and
+GGA branches: AO values, gradients, the V_xc conventions; exact exchange of a global hybrid; long-range exchange of a
+range-separated hybrid, omega = 0.4).  The AO values are also checked against analytic normalisation
 integrals and finite differences (tests/test_dft_oracle.py); the meta-GGA tau term and VV10 have no reference-held number
 a closed-form functional could reproduce (M06 / wB97M-V need libxc) and stay pinned by those checks only.
 """

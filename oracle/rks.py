@@ -14,9 +14,10 @@ class Tagged(np.ndarray):
     """ndarray with the attributes PySCF's tag_array attaches to a potential (ecoul, exc, vj, vk)."""
 
 
-def make_get_veff(layout, coords, weights, xc_code, get_j):
-    """``get_veff(mol, dm, ...)`` of an RKS object for the pure functional ``xc_code``; ``get_j(dm) -> J`` in the
-    molecule's AO basis."""
+def make_get_veff(layout, coords, weights, xc_code, get_j, get_k=None):
+    """``get_veff(mol, dm, ...)`` of an RKS object for the functional ``xc_code``; ``get_j(dm) -> J`` in the molecule's AO
+    basis; hybrids: ``get_k(dm, omega) -> K`` (omega = None: full range), combined as reference rks.py:232-250 does:
+    K = hyb K_full + (alpha - hyb) K_lr(omega), V -= K / 2, E_xc -= tr(D K) / 4."""
     kind = xc.xc_type(xc_code)
     ao = dft.eval_ao_mol(layout, coords, deriv=0 if kind == "LDA" else 1)       # [ncomp, nao, ngrids]
     w = np.asarray(weights, dtype=np.float64)
@@ -44,9 +45,17 @@ def make_get_veff(layout, coords, weights, xc_code, get_j):
         dm = np.asarray(dm, dtype=np.float64)
         nelec, exc, vxc = nr_rks(dm)
         vj = get_j(dm)
+        omega, alpha, hyb = xc.rsh_and_hybrid_coeff(xc_code)
+        vk = None
+        if abs(hyb) > 1e-10 or abs(alpha) > 1e-10:
+            vk = hyb * get_k(dm, None) if abs(hyb) > 1e-10 else 0.0
+            if abs(omega) > 1e-10:
+                vk = vk + (alpha - hyb) * get_k(dm, omega)
+            vxc = vxc - 0.5 * vk
+            exc -= 0.25 * float(np.einsum("ij,ji->", dm, vk))
         out = (vxc + vj).view(Tagged)
         out.ecoul = 0.5 * float(np.einsum("ij,ji->", dm, vj))
-        out.exc, out.vj, out.vk = exc, vj, None
+        out.exc, out.vj, out.vk = exc, vj, vk
         stats["nelec"] = nelec
         return out
     get_veff.stats = stats

@@ -184,11 +184,23 @@ class SlaterNumInt:
         return ()
 
 
+class _ClosedFormLibXC:
+    @staticmethod
+    def is_hybrid_xc(xc_code):
+        from oracle import xc
+        o, a, h = xc.rsh_and_hybrid_coeff(xc_code)
+        return abs(a) > 1e-10 or abs(h) > 1e-10
+
+    @staticmethod
+    def is_nlc(xc_code):
+        return False
+
+
 class ClosedFormNumInt:
-    """Stand-in for ``pyscf.dft.numint.NumInt`` + libxc for the two functionals whose energies the reference's tests
-    hold ("lda,vwn5", "pbe": jqc/pyscf/tests/test_dft.py:75-86): closed forms of oracle/xc.py behind the
+    """Stand-in for ``pyscf.dft.numint.NumInt`` + libxc for the functionals whose energies the reference's tests hold and that
+    have closed forms ("lda,vwn5", "pbe", "b3lyp", "wb97": jqc/pyscf/tests/test_dft.py:75-103,110-114): oracle/xc.py behind the
     ``eval_xc_eff`` signature (NumPy in, NumPy out, like a plain CPU PySCF NumInt)."""
-    libxc = _LibXCStub()
+    libxc = _ClosedFormLibXC()
 
     def _xc_type(self, xc_code):
         from oracle import xc
@@ -200,7 +212,8 @@ class ClosedFormNumInt:
         return xc.eval_xc_eff(xc_code, rho[0] if (rho.ndim == 2 and xc.xc_type(xc_code) == "LDA") else rho)
 
     def rsh_and_hybrid_coeff(self, xc_code, spin=0):
-        return 0.0, 0.0, 0.0
+        from oracle import xc
+        return xc.rsh_and_hybrid_coeff(xc_code)
 
     def nlc_coeff(self, xc_code):
         return ()

@@ -198,11 +198,13 @@ def test_rks_scf_through_apply_matches_cpu_oracle_scf():
     assert abs(e_default - e_cpu) < 1e-6, e_default - e_cpu
 
 
-@pytest.mark.parametrize("xc_code,e_ref", [("lda,vwn5", -75.9046410402), ("pbe", -76.3800182418)])
+@pytest.mark.parametrize("xc_code,e_ref", [("lda,vwn5", -75.9046410402), ("pbe", -76.3800182418), ("b3lyp", -76.4666495594),
+                                           ("wb97", -76.4486274326)])
 def test_reference_dft_energies_through_apply(kats, xc_code, e_ref):
-    """The reference's own known answers for the grid path (jqc/pyscf/tests/test_dft.py:75-86: H2O / def2-TZVPP, tolerance
-    1e-5): RKS through ``apply()`` -- device J (pair backend), rho_fun / vxc_fun on the MFMA kernels with the default
-    precision windows, the closed-form functional standing in for libxc, Becke grid of gto/grids.py."""
+    """The reference's own known answers for the grid path (jqc/pyscf/tests/test_dft.py:75-103: H2O / def2-TZVPP, tolerance
+    1e-5): RKS through ``apply()`` -- device J (pair backend) / J and K (tiled kernels; omega-B97: the long-range K-only
+    builds), rho_fun / vxc_fun on the MFMA kernels with the default precision windows, the closed-form functional standing in
+    for libxc, Becke grid of gto/grids.py."""
     import joltqc_amd.pyscf as jp
     from joltqc_amd.gto import mole
     from joltqc_amd.gto.grids import Grids

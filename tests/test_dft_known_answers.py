@@ -1,5 +1,7 @@
-"""The reference's own DFT energies pin the grid-path oracle: H2O / def2-TZVPP with "LDA,vwn5" and "PBE"
-(/root/reference/jqc/pyscf/tests/test_dft.py:75-86, e_ref -75.9046410402 / -76.3800182418, tolerance 1e-5 there).
+"""The reference's own DFT energies pin the grid-path oracle: H2O / def2-TZVPP with "LDA,vwn5", "PBE", "B3LYP" (spherical and
+Cartesian) and "HYB_GGA_XC_WB97" (/root/reference/jqc/pyscf/tests/test_dft.py:75-114: -75.9046410402, -76.3800182418,
+-76.4666495594, -76.4672144985, -76.4486274326; tolerance 1e-5 there): LDA, GGA, global-hybrid (exact exchange) and
+range-separated-hybrid (long-range exchange, omega = 0.4) Kohn-Sham paths.
 
 Everything on the path is this repo's CPU restatement: oracle/dft.py (AO values, rho, V_xc), oracle/xc.py (closed-form
 functionals), oracle/rks.py (nr_rks / get_veff), the Rys J oracle, the MD one-electron integrals and the Becke grid
@@ -15,28 +17,37 @@ from joltqc_amd.pyscf.basis import BasisLayout
 from oracle import dense, rks
 from standin_scf import RKS, Grids
 
-E_REF = {"lda,vwn5": -75.9046410402, "pbe": -76.3800182418}
+E_REF = {"lda,vwn5": -75.9046410402, "pbe": -76.3800182418, "b3lyp": -76.4666495594, "wb97": -76.4486274326}
 
 
-def oracle_rks_energy(kats, xc_code, nrad, ntheta):
-    mol = mole.Mole(atom=kats["h2o_def2tzvpp"]["atom"], basis="def2-tzvpp")
+def oracle_rks_energy(kats, xc_code, nrad, ntheta, cart=False):
+    mol = mole.Mole(atom=kats["h2o_def2tzvpp"]["atom"], basis="def2-tzvpp", cart=cart)
     lay = BasisLayout.from_mol(mol)
     S, T, V = dense.int1e_mol(lay, mol)
     q = dense.canonical_quartets(lay)
     g = G.Grids(mol, nrad=nrad, ntheta=ntheta).build()
     mf = RKS(mol, T + V, S, Grids(g.coords, g.weights), xc=xc_code)
     mf.get_veff = rks.make_get_veff(lay, g.coords, g.weights, xc_code,
-                                    lambda dm: dense.get_jk(lay, dm, 1, with_k=False, quartets=q)[0])
+                                    lambda dm: dense.get_jk(lay, dm, 1, with_k=False, quartets=q)[0],
+                                    lambda dm, omega: dense.get_jk(lay, dm, 1, with_j=False, quartets=q, omega=omega)[1])
     e = mf.kernel()
     assert mf.converged
     return e, mf.get_veff.stats["nelec"]
 
 
-@pytest.mark.parametrize("xc_code", ["lda,vwn5", "pbe"])
-def test_h2o_def2tzvpp_rks_energy_matches_the_reference(kats, xc_code):
+@pytest.mark.parametrize("xc_code,grid", [("lda,vwn5", (60, 16)), ("pbe", (90, 24)), ("b3lyp", (60, 16)), ("wb97", (90, 24))])
+def test_h2o_def2tzvpp_rks_energy_matches_the_reference(kats, xc_code, grid):
     # grid refined until the energy is stable: (60, 16) -> (90, 24) moves it by 9e-8 / 4e-7 Eh, (90, 24) sits 1e-9 / 6e-8 Eh
     # from the reference's number (which carries PySCF's own level-5 grid error); the bar is ten times tighter than the
     # reference's own 1e-5
-    e, nelec = oracle_rks_energy(kats, xc_code, 90, 24)
-    assert abs(nelec - 10.0) < 1e-7, nelec
+    # measured differences to the reference's numbers at (60, 16) / (90, 24): LDA 8e-8 / 1e-9, PBE 5e-7 / 6e-8, B3LYP 4.5e-7 / 3e-9,
+    # omega-B97 2e-6 / 6e-8 (the cheaper grid is used where it is already inside the bar)
+    e, nelec = oracle_rks_energy(kats, xc_code, *grid)
+    assert abs(nelec - 10.0) < 1e-6, nelec
     assert abs(e - E_REF[xc_code]) < 1e-6, e - E_REF[xc_code]
+
+
+def test_h2o_def2tzvpp_b3lyp_cartesian_energy_matches_the_reference(kats):
+    """test_dft.py:110-114 (mol_cart): -76.4672144985 -- hybrid exchange, GGA and the Cartesian d / f shells together."""
+    e, nelec = oracle_rks_energy(kats, "b3lyp", 90, 24, cart=True)
+    assert abs(nelec - 10.0) < 1e-7 and abs(e + 76.4672144985) < 1e-6, (e, nelec)
