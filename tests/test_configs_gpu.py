@@ -1,4 +1,6 @@
-"""BASELINE configs 4 and 5 at their own sizes, on the GPU (driver: pytest -m gpu).
+"""BASELINE configs 3, 4 and 5 at their own sizes, on the GPU (driver: pytest -m gpu).
+
+Config 3 -- "Taxol RKS B3LYP/def2-SVP": the 112-atom stand-in, whole SCF through apply() (last test of this file).
 
 Config 4 -- "Valinomycin RKS wB97M-V/def2-TZVPP mixed FP32/FP64 (VV10 nlc path)": the 166-atom CHNO stand-in
 (Valinomycin has 168 atoms and its geometry is not in the reference) with def2-TZVPP:
@@ -226,3 +228,39 @@ def test_config5_425_atoms_svp_one_rank_and_two_ranks():
     assert float((sj.cuda() - vj).abs().max()) < 1e-11 * sc and float((sk.cuda() - vk).abs().max()) < 1e-11 * sc
     assert res[0][1] + res[1][1] == n_all                       # every dispatched quartet on exactly one rank
     assert min(res[0][1], res[1][1]) > 0.4 * n_all              # balanced to 60 / 40 or better
+
+
+def test_config3_112_atoms_b3lyp_svp_scf_through_apply():
+    """BASELINE config 3 -- "Taxol RKS B3LYP/def2-SVP (J/K + eval_rho / eval_vxc grid path)" on the 112-atom stand-in: a whole
+    Kohn-Sham SCF through ``apply()`` (hybrid: J and K from the tiled kernels every iteration, incremental rho / V_xc on the MFMA
+    kernels, one-electron integrals from the device) with the closed-form B3LYP standing in for libxc.  No reference-held energy
+    exists for this molecule: the run must converge, integrate the density to N_e, and the default mixed FP32 / FP64 windows
+    of ``apply()`` must agree with an all-FP64 run to the reference's own 1e-5 bar of its energy tests."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from joltqc_amd.gto.grids import Grids
+    from joltqc_amd.pyscf import int1e
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from standin_scf import RKS, ClosedFormNumInt
+    mol = mole.Mole(atom=mole.read_xyz(os.path.join(ROOT, "joltqc_amd/data/molecules/0112-elongated-nitrogenous.xyz")),
+                    basis="def2-svp")
+    S, T, V = (x.cpu().numpy() for x in int1e.int1e(BasisLayout.from_mol(mol, alignment=1), mol))
+    energies = {}
+    for label, cfg in (("default", None), ("fp64", {"jk": {"cutoff_fp32": 1e-13, "cutoff_fp64": 1e-13},
+                                                     "dft": {"cutoff_fp32": 1e-13, "cutoff_fp64": 1e-13}})):
+        c = jp.get_default_config()
+        if cfg:
+            c.update(cfg)
+        mf = RKS(mol, T + V, S, Grids(mol, 30, 8), xc="b3lyp", numint=ClosedFormNumInt())
+        mf.max_cycle = 40
+        mf = jp.apply(mf, c)
+        t = time.time()
+        e = mf.kernel()
+        assert mf.converged, (label, mf.cycles)
+        D = np.asarray(mf.make_rdm1())
+        rho = mf._numint.get_rho(mol, D, mf.grids)
+        rho = rho.cpu().numpy() if hasattr(rho, "cpu") else np.asarray(rho)
+        nelec = float((rho[: len(mf.grids.weights)] * mf.grids.weights).sum())
+        assert abs(nelec - mol.nelectron) < 2e-3 * mol.nelectron, (label, nelec)     # (30 x 128 points per atom)
+        energies[label] = (e, mf.cycles, time.time() - t)
+    assert abs(energies["default"][0] - energies["fp64"][0]) < 1e-5, energies
