@@ -34,6 +34,8 @@ def run(wl="0112-elongated-nitrogenous", tol=1e-10, verbose=True, modes=(("jk", 
                 key = "%d%d%d%d" % ang
                 os.environ["JQC_ONLY_CLASS"] = key
                 os.environ.pop("JQC_JK_ALGO", None)
+                if os.environ.get("JQC_VERIFY_ALGO"):          # diagnostics: this variant code instead of the table's choice
+                    os.environ["JQC_JK_ALGO"] = "v%d" % int(os.environ["JQC_VERIFY_ALGO"], 0)
                 router.gen_jk_kernel.cache_clear()
                 jkmod.KCHUNK_MAX, jkmod.NSPLIT_MAX = kc, ns
                 g = jkmod.generate_jk_kernel(lay, 1e-13, 1e-13)
