@@ -20,6 +20,61 @@ def _strict(x):
     return np.asarray(x)
 
 
+def atomic_density_guess(mol, cycles=40):
+    """Initial density matrix for large molecules (the role of PySCF's ``init_guess='minao'`` / ``'atom'``): superposition of
+    spherically averaged free-atom densities, block-diagonal in ``mol``'s AO order.  One small restricted SCF per element with
+    fractional aufbau occupations (a degenerate level shares its electrons evenly, so the density stays spherical), run on the CPU
+    oracle (``oracle/dense.py``; 5-36 AOs per atom).  The core-Hamiltonian guess of ``kernel`` does not converge for a
+    100-atom molecule (``tools/scf_probe.py``: the energy swings by thousands of hartree for 50 cycles)."""
+    from oracle import dense
+    from joltqc_amd.gto import mole as gmole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    atom_dm = {}
+    for ia in range(mol.natm):
+        sym = mol.atom_symbol(ia)
+        if sym in atom_dm:
+            continue
+        atom = gmole.Mole(atom=[(sym, (0.0, 0.0, 0.0))], basis=mol.basis, cart=mol.cart, unit="B")
+        lay = BasisLayout.from_mol(atom, alignment=1)
+        S, T, V = dense.int1e_mol(lay, atom)
+        h = T + V
+        s, U = np.linalg.eigh(S)
+        X = U[:, s > 1e-10] / np.sqrt(s[s > 1e-10])
+        q = dense.canonical_quartets(lay)
+        nelec = int(atom.atom_charges()[0])
+
+        def density(F):
+            e, c = np.linalg.eigh(X.T @ F @ X)
+            c = X @ c
+            occ = np.zeros(len(e))
+            left, i = float(nelec), 0
+            while left > 1e-12 and i < len(e):
+                j = i
+                while j + 1 < len(e) and e[j + 1] - e[i] < 1e-5:
+                    j += 1
+                g = j - i + 1
+                fill = min(left, 2.0 * g)
+                occ[i:j + 1] = fill / g
+                left -= fill
+                i = j + 1
+            return (c * occ) @ c.T
+
+        dm = density(h)
+        for _ in range(cycles):
+            vj, vk = dense.get_jk(lay, dm, 1, quartets=q)
+            dm = 0.5 * dm + 0.5 * density(h + np.asarray(vj) - 0.5 * np.asarray(vk))
+        atom_dm[sym] = dm
+    nao = mol.nao
+    dm = np.zeros((nao, nao))
+    loc = np.asarray(mol.ao_loc_nr())
+    atom_of = np.asarray(mol._bas[:, 0])
+    for ia in range(mol.natm):
+        sh = np.nonzero(atom_of == ia)[0]
+        a0, a1 = int(loc[sh[0]]), int(loc[sh[-1] + 1])
+        dm[a0:a1, a0:a1] = atom_dm[mol.atom_symbol(ia)]
+    return dm
+
+
 class RHF:
     def __init__(self, mol, hcore=None, ovlp=None, int1e=None):
         self.mol = mol

@@ -241,9 +241,10 @@ def test_config3_112_atoms_b3lyp_svp_scf_through_apply():
     from joltqc_amd.gto.grids import Grids
     from joltqc_amd.pyscf import int1e
     from joltqc_amd.pyscf.basis import BasisLayout
-    from standin_scf import RKS, ClosedFormNumInt
+    from standin_scf import RKS, ClosedFormNumInt, atomic_density_guess
     mol = mole.Mole(atom=mole.read_xyz(os.path.join(ROOT, "joltqc_amd/data/molecules/0112-elongated-nitrogenous.xyz")),
                     basis="def2-svp")
+    dm0 = atomic_density_guess(mol)          # (the core-Hamiltonian guess does not converge at this size: tools/scf_probe.py)
     S, T, V = (x.cpu().numpy() for x in int1e.int1e(BasisLayout.from_mol(mol, alignment=1), mol))
     energies = {}
     for label, cfg in (("default", None), ("fp64", {"jk": {"cutoff_fp32": 1e-13, "cutoff_fp64": 1e-13},
@@ -255,7 +256,7 @@ def test_config3_112_atoms_b3lyp_svp_scf_through_apply():
         mf.max_cycle = 40
         mf = jp.apply(mf, c)
         t = time.time()
-        e = mf.kernel()
+        e = mf.kernel(dm0=dm0)
         assert mf.converged, (label, mf.cycles)
         D = np.asarray(mf.make_rdm1())
         rho = mf._numint.get_rho(mol, D, mf.grids)

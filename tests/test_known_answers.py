@@ -25,3 +25,25 @@ def test_h2o_def2tzvpp_rhf_energy(kats, cart, key):
     assert mf.converged
     # the reference prints 10 decimals and asserts 1e-5; this build's bar is 1e-8 (north star)
     assert abs(e - k[key]) < 1e-8, e - k[key]
+
+
+def test_atomic_density_guess_starts_the_same_scf(kats):
+    """The initial guess the large-molecule GPU tests use (``standin_scf.atomic_density_guess``): block-diagonal, symmetric,
+    integrates to the electron count, and the SCF started from it lands on the energy of the core-Hamiltonian start."""
+    from standin_scf import atomic_density_guess
+    mol = mole.Mole(atom=kats["h2o_def2tzvpp"]["atom"], basis="def2-svp")
+    lay = BasisLayout.from_mol(mol)
+    S, T, V = dense.int1e_mol(lay, mol)
+    dm0 = atomic_density_guess(mol)
+    assert abs(np.trace(dm0 @ S) - mol.nelectron) < 1e-10 and np.abs(dm0 - dm0.T).max() < 1e-14
+    loc = mol.ao_loc_nr()
+    o_end = int(loc[np.nonzero(mol._bas[:, 0] == 0)[0][-1] + 1])
+    assert np.abs(dm0[:o_end, o_end:]).max() == 0.0                       # no inter-atomic blocks
+    q = dense.canonical_quartets(lay)
+    e = []
+    for d0 in (None, dm0):
+        mf = RHF(mol, T + V, S)
+        mf.get_jk = lambda m, dm, hermi=1, **kw: dense.get_jk(lay, dm, hermi, quartets=q)
+        e.append(mf.kernel(dm0=d0))
+        assert mf.converged
+    assert abs(e[0] - e[1]) < 1e-9
