@@ -166,16 +166,56 @@ def resolved_algo(ang, do_j, do_k, rys_lr, fp32, algo):
     return _resolved.get((tuple(ang), bool(do_j), bool(do_k), bool(rys_lr), bool(fp32), int(algo)), int(algo))
 
 
+_fallbacks = None      # {build key: variant the build resolved to}: the LDS-overflow fallbacks already found for these sources
+
+
+def _fallback_file():
+    return os.path.join(_lib.KERNEL_CACHE, "lds_fallbacks.txt")
+
+
+def _known_fallbacks():
+    """Fallbacks recorded next to the code objects (one line per build: source tag, key, resolved variant).  A variant that does
+    not fit LDS leaves no code object behind, so without this record every process would compile it again just to see it fail
+    (seconds per build, on the GPU box inside the first J/K call); the ahead-of-time build writes the record."""
+    global _fallbacks
+    if _fallbacks is None:
+        _fallbacks = {}
+        tag = _lib.lib().jqc_source_tag().decode()
+        try:
+            with open(_fallback_file()) as f:
+                for line in f:
+                    w = line.split()
+                    if len(w) == 3 and w[0] == tag:
+                        _fallbacks[w[1]] = int(w[2])
+        except OSError:
+            pass
+    return _fallbacks
+
+
+def _fallback_key(ang, do_j, do_k, rys_lr, fp32, want):
+    return "%d%d%d%d:%d%d%d%d:%d" % (*ang, bool(do_j), bool(do_k), bool(rys_lr), bool(fp32), want)
+
+
 @lru_cache(maxsize=None)
 def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None, compile_only=False):
     ang = tuple(int(x) for x in ang)
     if algo is None:
         algo = select_algo(ang, fp32)
     want = int(algo)
+    fkey = _fallback_key(ang, do_j, do_k, rys_lr, fp32, want)
+    algo = _known_fallbacks().get(fkey, want)
     while True:
         try:
             h = _lib.gen_jk_kernel(ang, do_j, do_k, rys_lr, fp32, algo, compile_only)
             _resolved[(ang, bool(do_j), bool(do_k), bool(rys_lr), bool(fp32), want)] = int(algo)
+            if int(algo) != want and _known_fallbacks().get(fkey) != int(algo):
+                _fallbacks[fkey] = int(algo)
+                try:        # (one short O_APPEND write per entry: safe from the parallel workers of the ahead-of-time build)
+                    fd = os.open(_fallback_file(), os.O_WRONLY | os.O_APPEND | os.O_CREAT, 0o644)
+                    os.write(fd, ("%s %s %d\n" % (_lib.lib().jqc_source_tag().decode(), fkey, int(algo))).encode())
+                    os.close(fd)
+                except OSError:
+                    pass
             return h
         except RuntimeError as e:
             # the ONE expected failure: several ket pairs per iteration (or the j-in-registers form) do not fit LDS for this
