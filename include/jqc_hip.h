@@ -204,7 +204,10 @@ int jqc_schwarz(int li, int lj, const double* basis_d, const uint32_t* pair_sh_d
  * jqc_dft_vxc        replaces eval_vxc (jqc/backend/rks.py:104-160, dft/eval_vxc.cu:87): vmat[nao*nao] += the FULL
  *   symmetric V (the reference accumulates the upper triangle and symmetrises afterwards); wv[ndim][ngrids] already
  *   contains the quadrature weights.
- * jqc_vv10           replaces vv10_kernel (jqc/backend/rks.py:250-335, dft/vv10.cu:29): F,U,W double[ngrids]. */
+ * jqc_vv10           replaces vv10_kernel (jqc/backend/rks.py:250-335, dft/vv10.cu:29): F,U,W double[ngrids].
+ *   fp32: 0 = FP64 inner loop, 1 = FP32 inner loop (the reference's), 3 = FP32 and the caller guarantees K, Kp >= 1e-3 at
+ *   every point (true for VV10's K = b k_F-type factors of points with rho >= 1e-10, padding included): the reference's
+ *   test `g' (g gt)^2 > 1e-30` (vv10.cu:104) can then not fail and is not evaluated. */
 int jqc_dft_ao_screen(const double* coords_d, int ngrids, const double* basis_d, const int32_t* ao_loc_d, int nbas,
                       float log_cutoff, uint16_t* shell_list_d, int32_t* row_of_d, int32_t* nshl_d, int32_t* nrow_d,
                       float* shell_la_d, void* stream);

@@ -1103,7 +1103,32 @@ int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, co
     // (measured, N = 262 144, FP32 inner loop: 1 point per lane 49.0 ms, 2: 46.7 ms, 4: 42.3 ms; profiles/r03_vv10_outer_points_per_lane_1_2_4.txt)
     static const int nout = getenv("JQC_VV10_NOUT") ? atoi(getenv("JQC_VV10_NOUT")) : 4;
     const int nb = ngrids / NG;
-    if (fp32 && nout == 2)
+    // JQC_VV10_PK = 0: the scalar-source FP32 inner loop (A/B); default: the packed-FP32 form with 4 outer points per lane
+    // (N = 262 144: scalar 42.2 ms; packed 2 / 4 / 8 points per lane, inner loop split automatically: 24.7 / 23.2 / 62 ms;
+    //  N = 1 048 576: 541 -> 366 ms; profiles/r03_vv10_packed_fp32.txt)
+    static const int pk = getenv("JQC_VV10_PK") ? atoi(getenv("JQC_VV10_PK")) : 4;
+    if (fp32 && (pk == 2 || pk == 4 || pk == 8)) {
+        // split the inner loop over blockIdx.y until the grid has ~8 workgroups per CU (JQC_VV10_SPLIT overrides)
+        const int nwg = (nb + pk - 1) / pk, njb = vvngrids / NG;
+        static const int split_env = getenv("JQC_VV10_SPLIT") ? atoi(getenv("JQC_VV10_SPLIT")) : 0;
+        int nsplit = split_env > 0 ? split_env : (2048 + nwg - 1) / nwg;
+        nsplit = std::max(1, std::min(nsplit, njb));
+        const int jchunk = ((njb + nsplit - 1) / nsplit) * NG;
+        nsplit = (vvngrids + jchunk - 1) / jchunk;
+        if (nsplit > 1) {
+            HIP_OK(hipMemsetAsync(F_d, 0, sizeof(double) * ngrids, (hipStream_t)stream));
+            HIP_OK(hipMemsetAsync(U_d, 0, sizeof(double) * ngrids, (hipStream_t)stream));
+            HIP_OK(hipMemsetAsync(W_d, 0, sizeof(double) * ngrids, (hipStream_t)stream));
+        }
+#define VV10_PK(N, C) hipLaunchKernelGGL((vv10_kernel_pk<N, C>), dim3(nwg, nsplit), dim3(256), 0, (hipStream_t)stream, F_d, U_d, \
+                                        W_d, vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids, jchunk)
+        const bool check = !(fp32 & 2);             // fp32 = 3: the denominator test cannot fail (include/jqc_hip.h)
+        if (pk == 8) { if (check) VV10_PK(8, true); else VV10_PK(8, false); }
+        else if (pk == 4) { if (check) VV10_PK(4, true); else VV10_PK(4, false); }
+        else { if (check) VV10_PK(2, true); else VV10_PK(2, false); }
+#undef VV10_PK
+    }
+    else if (fp32 && nout == 2)
         hipLaunchKernelGGL((vv10_kernel_n<float, 2>), dim3((nb + 1) / 2), dim3(256), 0, (hipStream_t)stream, F_d, U_d, W_d,
                            vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids);
     else if (fp32 && nout == 4)

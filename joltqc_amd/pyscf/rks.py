@@ -352,11 +352,14 @@ def vv10_sums(outer, inner, fp32=True, shard=None):
     b0, b1 = (nblk * rank) // nranks, (nblk * (rank + 1)) // nranks
     if b1 > b0 and ni_pad:
         o = outer[:, b0 * NG:b1 * NG].contiguous()
+        # FP32 inner loop: with K, Kp >= 1e-3 everywhere the denominator g' (g gt)^2 >= 4e-15 cannot fail the reference's
+        # `> 1e-30` test (vv10.cu:104), which the kernel then skips (mode 3, include/jqc_hip.h); one device reduction decides
+        mode = 0 if not fp32 else (3 if float(torch.minimum(o[4].min(), inner[4].min())) >= 1e-3 else 1)
         res = torch.empty((3, (b1 - b0) * NG), dtype=torch.float64, device=dev)
         _lib.check(L.jqc_vv10(res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(), inner[:3].contiguous().data_ptr(),
                               o[:3].contiguous().data_ptr(), inner[3].data_ptr(), o[3].contiguous().data_ptr(),
                               o[4].contiguous().data_ptr(), inner[4].data_ptr(), inner[5].data_ptr(), ni_pad,
-                              (b1 - b0) * NG, int(bool(fp32)), _lib.stream_ptr()))
+                              (b1 - b0) * NG, mode, _lib.stream_ptr()))
         out[:, b0 * NG:b1 * NG] = res
     if nranks > 1:
         import torch.distributed as dist

@@ -125,6 +125,55 @@ def test_vv10_kernel_and_driver():
     assert np.abs(v32.cpu().numpy() - v_ref).max() < 2e-4 * max(1.0, np.abs(v_ref).max())
 
 
+def test_vv10_pair_sums_kernel_modes():
+    """``vv10_sums`` / ``jqc_vv10`` directly on synthetic points, uneven outer / inner sizes (inner loop split over several
+    workgroups, partial blocks): the packed-FP32 kernel with the reference's denominator test (mode 1), without it (mode 3,
+    chosen by ``vv10_sums`` when every K, Kp >= 1e-3) and the FP64 kernel against a NumPy restatement of dft/vv10.cu:86-117;
+    points with K = Kp = 0 on top of each other (denominator 0) must contribute nothing, as in the reference."""
+    import torch
+    from joltqc_amd.backend import lib as L
+    from joltqc_amd.pyscf import rks
+    dev = L.require_gpu()
+    rng = np.random.default_rng(11)
+    no, ni = 3 * 256, 7 * 256
+
+    def make(kmin):
+        outer = np.vstack([rng.random((3, no)) * 6, rng.random((1, no)) + 0.5, rng.random((1, no)) + kmin])
+        inner = np.vstack([rng.random((3, ni)) * 6, rng.random((1, ni)) + 0.5, rng.random((1, ni)) + kmin, rng.random((1, ni)) * 1e-2])
+        return outer, inner
+
+    def ref(outer, inner):
+        d = outer[:3, :, None] - inner[:3, None, :]
+        R2 = (d ** 2).sum(0)
+        g = outer[3][:, None] * R2 + outer[4][:, None]
+        gp = inner[3][None, :] * R2 + inner[4][None, :]
+        gt = g + gp
+        den = gp * (g * gt) ** 2
+        T = np.where(den > 1e-30, inner[5][None, :] / np.where(den > 1e-30, den, 1.0), 0.0)
+        return np.stack([-1.5 * (T * g * gt).sum(1), (T * (g + gt)).sum(1), (T * R2 * (g + gt)).sum(1)])
+
+    outer, inner = make(0.5)
+    want = ref(outer, inner)
+    o_d, i_d = torch.from_numpy(outer).to(dev), torch.from_numpy(inner).to(dev)
+    got64 = rks.vv10_sums(o_d, i_d, fp32=False).cpu().numpy()
+    assert np.abs(got64 - want).max() < 1e-11 * np.abs(want).max()
+    got32 = rks.vv10_sums(o_d, i_d, fp32=True).cpu().numpy()            # K >= 0.5: mode 3
+    assert np.abs(got32 - want).max() < 2e-5 * np.abs(want).max()
+    lib = L.lib()
+    out = torch.empty((3, no), dtype=torch.float64, device=dev)
+    L.check(lib.jqc_vv10(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), i_d[:3].contiguous().data_ptr(),
+                         o_d[:3].contiguous().data_ptr(), i_d[3].data_ptr(), o_d[3].contiguous().data_ptr(),
+                         o_d[4].contiguous().data_ptr(), i_d[4].data_ptr(), i_d[5].data_ptr(), ni, no, 1, L.stream_ptr()))
+    assert np.abs(out.cpu().numpy() - got32).max() < 1e-12 * np.abs(want).max()      # the test changes no value when it cannot fail
+    # coinciding points with K = Kp = 0: denominator exactly 0 -> the pair is skipped (mode 1 is chosen: K < 1e-3)
+    outer[4, :5] = 0.0
+    inner[4, :5] = 0.0
+    inner[:3, :5] = outer[:3, :5]
+    want = ref(outer, inner)
+    got = rks.vv10_sums(torch.from_numpy(outer).to(dev), torch.from_numpy(inner).to(dev), fp32=True).cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+
+
 def test_incremental_nr_rks_with_slater_exchange():
     """nr_rks plumbing (incremental rho / V_xc caches) with an analytic LDA functional standing in for libxc."""
     import torch
