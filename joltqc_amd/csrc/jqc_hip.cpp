@@ -58,19 +58,20 @@ struct Kernel {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     int li = 0, lj = 0, lk = 0, ll = 0, fp32 = 0, algo = 0, nroots = 1;
+    int per_wg = 0;         // gradient kernels: quartets per workgroup pass (0: one quartet per lane)
 };
 // a deque: handles stay valid and references to entries are not moved when another thread registers a kernel; every
 // access to the container itself (size, lookup, push_back) happens under g_mu, the launchers copy the few fields they need
 std::deque<Kernel> g_kernels;
 std::map<std::string, int> g_by_key;
 
-struct KernelView { hipFunction_t fn; int fp32, algo, nroots; };
+struct KernelView { hipFunction_t fn; int fp32, algo, nroots, per_wg; };
 bool kernel_view(int handle, KernelView& v)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (handle < 0 || handle >= (int)g_kernels.size() || !g_kernels[handle].fn) return false;
     const Kernel& k = g_kernels[handle];
-    v = KernelView{k.fn, k.fp32, k.algo, k.nroots};
+    v = KernelView{k.fn, k.fp32, k.algo, k.nroots, k.per_wg};
     return true;
 }
 
@@ -818,13 +819,48 @@ int jqc_gen_pair_vj_kernel(int li, int lj, int lk, int ll, int rys_lr, int compi
     return h;
 }
 
+// quartets one workgroup of the cooperative gradient kernel takes per pass (the constants G / QBYTES of jk_grad.hip)
+static int grad_quartets_per_pass(int li, int lj, int lk, int ll)
+{
+    auto nf = [](int l) { return (l + 1) * (l + 2) / 2; };
+    const int t = nf(li) * nf(lj);
+    const int gsz = (li + 2) * (lj + 2) * (lk + 2) * (ll + 1), gsb = (li + 1) * (lj + 1) * (lk + 1) * (ll + 1);
+    const int nrg = (li + lj + lk + ll + 1) / 2 + 1;
+    const int qbytes = (3 * (gsz + 4 * gsb) + 2 * nrg + nf(lk) * nf(ll) + 9) * 8;
+    auto gcap = [&](int budget) { const int g = budget / qbytes; return g < 256 / t ? (g < 1 ? 1 : g) : 256 / t; };
+    static const bool two_wg_off = getenv("JQC_EXTRA_DEFS") && strstr(getenv("JQC_EXTRA_DEFS"), "-DGRAD_TWO_WG=0");
+    const bool two_wg = !two_wg_off && nf(lk) * nf(ll) <= 18 && 4 * gcap(78 * 1024) >= 3 * gcap(150 * 1024);
+    return two_wg ? gcap(78 * 1024) : gcap(150 * 1024);
+}
+
 int jqc_gen_jk_grad_kernel(int li, int lj, int lk, int ll, int rys_lr, int compile_only)
 {
     std::lock_guard<std::mutex> lk_(g_mu);
     if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
+    // Which form (jk_grad.hip): the cooperative one (GRAD_COOP) where it measured faster on the 112-atom def2-TZVPP gradient
+    // (39 of the 65 s..f classes, profiles/r03_grad_forms_per_class_112atoms_tzvpp.txt: everything with a ket block of >= 18
+    // components and most (.. | dp), (.. | pp), (.. | ds) classes with a d or f bra), the one-quartet-per-lane form for the rest
+    // (small ket blocks: three barriers per root buy nothing).  g classes (not in that workload): by the size of the ket block.
+    // JQC_GRAD_COOP=0 / 1 forces one form on every class (A/B).
+    static const int coop_env = getenv("JQC_GRAD_COOP") ? atoi(getenv("JQC_GRAD_COOP")) : -1;
+    static const char* const kCoopWins[] = {"1000", "2022", "2111", "2120", "2121", "2122", "2211", "2220", "2221", "2222",
+        "3021", "3022", "3031", "3032", "3111", "3120", "3121", "3122", "3130", "3131", "3132", "3133", "3211", "3220",
+        "3221", "3222", "3230", "3231", "3232", "3233", "3310", "3311", "3320", "3321", "3322", "3330", "3331", "3332",
+        "3333"};
+    int coop = coop_env;
+    if (coop < 0) {
+        if (li <= 3) {
+            char c4[8];
+            snprintf(c4, sizeof c4, "%d%d%d%d", li, lj, lk, ll);
+            coop = 0;
+            for (const char* w : kCoopWins) coop |= !strcmp(w, c4);
+        } else {
+            coop = ((lk + 1) * (lk + 2) / 2) * ((ll + 1) * (ll + 2) / 2) >= 18;
+        }
+    }
     char key[96];
-    snprintf(key, sizeof key, "jkgrad_%d%d%d%d_lr%d", li, lj, lk, ll, rys_lr);
+    snprintf(key, sizeof key, coop ? "jkgrad_%d%d%d%d_lr%d_coop" : "jkgrad_%d%d%d%d_lr%d", li, lj, lk, ll, rys_lr);
     auto it = g_by_key.find(key);
     if (it != g_by_key.end() && (compile_only || g_kernels[it->second].fn)) return it->second;
     char entry[64];
@@ -834,13 +870,14 @@ int jqc_gen_jk_grad_kernel(int li, int lj, int lk, int ll, int rys_lr, int compi
         int rc = compile_to("jk_grad.hip", {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
                                             "-DLK=" + std::to_string(lk), "-DLL=" + std::to_string(ll),
                                             "-DRYS_LR=" + std::to_string(rys_lr), "-DFP32=0", "-DDO_J=1", "-DDO_K=1",
-                                            std::string("-DKNAME=") + entry}, out);
+                                            "-DGRAD_COOP=" + std::to_string(coop), std::string("-DKNAME=") + entry}, out);
         if (rc) return rc;
     }
     Kernel k;
     k.key = key;
     k.li = li; k.lj = lj; k.lk = lk; k.ll = ll; k.algo = JQC_ALGO_JKGRAD;
     k.nroots = (li + lj + lk + ll + 1) / 2 + 1;          // one derivative: one more order
+    if (coop) k.per_wg = grad_quartets_per_pass(li, lj, lk, ll);
     if (!compile_only) {
         int rc = load_kernel(out, entry, k);
         if (rc) return rc;
@@ -874,7 +911,8 @@ int jqc_jk_grad_launch(int handle, int nao, const double* basis_d, const double*
     void* args[] = {&nao, &basis_d, &dm_d, &n_dm, &grad_d, &shell_atom_d, &natm, &nrep, &j_factor, &k_factor, &omega,
                     &quartets_d, &ntasks_d, &qstride, &cheb, &large};
     const int block = 256;
-    int64_t blocks = (ntasks_max + block - 1) / block;
+    const int per = k.per_wg > 0 ? k.per_wg : block;          // quartets one workgroup takes per pass
+    int64_t blocks = (ntasks_max + per - 1) / per;
     const int64_t cap = 256 * 64;  // grid-stride beyond this
     if (blocks > cap) blocks = cap;
     HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)blocks, 1, 1, block, 1, 1, 0, (hipStream_t)stream, args, nullptr));

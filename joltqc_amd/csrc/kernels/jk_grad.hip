@@ -293,9 +293,364 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
     }
 }
 
+#ifndef GRAD_COOP
+#define GRAD_COOP 0
+#endif
 #ifndef KNAME
 #define KNAME jk_grad
 #endif
+#if GRAD_COOP
+// =====================================================================================================================
+// Cooperative form (round 3): a quartet is worked on by T = nf_i * nf_j lanes (one per bra Cartesian pair, as the row-lane J/K
+// kernels of jk_tile.hip), G = 256 / T quartets per pass of a workgroup.  The one-quartet-per-lane form above keeps the 1-D
+// arrays of a lane (3 axes x GSB x 4 doubles: 3.4 KB for (dp|dp), 31 KB for (ff|ff)) in scratch and reads twelve of them per
+// integral and root, i.e. it runs at the speed of the scratch path.  Here they live in LDS, once per quartet:
+//   per primitive combination:  Rys roots by NRG lanes of the quartet                                     -> sRW
+//   per root:  A1  one lane per (quartet, axis, row i): that row of the extended 1-D array (axis_row_g)   -> sExt
+//              A2  all lanes of the quartet: derivative records {g, dg/dA, dg/dB, dg/dC} per index tuple   -> sQ
+//              B   lane (ci, cj): loop over the ket components, three 32-byte record reads per component,
+//                  nine derivative sums in registers; the effective density from D_ij (register), D_kl (LDS, shared by the
+//                  quartet's lanes) and the lane's own rows of D_ik, D_il, D_jk, D_jl (registers)
+//   per quartet:  the nine sums of its T lanes are added in LDS, twelve global atomics per quartet instead of per lane.
+// Quartets of one pass may have different primitive counts: the combination loop runs to the largest count of the pass.
+constexpr int T = NFI * NFJ;
+// quartets per pass: as many as the 256 lanes hold, capped by the LDS their 1-D arrays take.  Two workgroups per CU (78 KB each,
+// two waves per SIMD: one workgroup's barriers and thin phases hide behind the other's phase B) where that costs at most a
+// quarter of the lanes, otherwise one workgroup with up to 150 KB.  (The host launcher repeats this arithmetic: jqc_hip.cpp,
+// grad_quartets_per_pass.)
+constexpr int QBYTES = (3 * (GSZ + 4 * GSB) + 2 * NRG + NFK * NFL + 9) * 8;
+constexpr int gcap(int budget) { return budget / QBYTES < 256 / T ? (budget / QBYTES < 1 ? 1 : budget / QBYTES) : 256 / T; }
+#ifndef GRAD_TWO_WG
+#define GRAD_TWO_WG 1
+#endif
+// (measured: the 256-register cap of two workgroups per CU pays up to a ket block of 18 components -- (fp|dp) 1 334 -> 967 ms --,
+//  larger ket blocks spill under it -- (fd|dd) 322 -> 504 ms -- and keep one workgroup with 512 registers per lane)
+constexpr bool TWO_WG = GRAD_TWO_WG && NFK * NFL <= 18 && 4 * gcap(78 * 1024) >= 3 * gcap(150 * 1024);
+constexpr bool P_REGS = NFK * NFL <= 18;         // effective density of the lane's components held in registers for the whole pass
+constexpr int G = TWO_WG ? gcap(78 * 1024) : gcap(150 * 1024);
+#if ((LK + 1) * (LK + 2) / 2) * ((LL + 1) * (LL + 2) / 2) <= 100
+#define BUNROLL _Pragma("unroll")          // ket loop of phase B with compile-time record offsets
+#else
+#define BUNROLL _Pragma("nounroll")
+#endif
+static_assert(T <= 256, "a quartet must fit one workgroup");
+
+__device__ __forceinline__ void rys_root_one_g(real x, real theta, real omega, const int r, const real* __restrict__ cheb,
+                                               const real* __restrict__ large, real& root, real& weight)
+{
+    real tf = 1, stf = 1;
+    x *= theta;
+#if RYS_LR
+    {
+        const real w2 = omega * omega;
+        tf = w2 / (w2 + theta);
+        x *= tf;
+        stf = sqrt(tf);
+    }
+#endif
+    if (x >= real(5 * NRG + 35)) {
+        const real isx = rsqrt(x);
+        root = large[2 * r] * isx * isx * tf;
+        weight = large[2 * r + 1] * isx * stf;
+        return;
+    }
+    const int it = (int)(x * real(0.4));
+    const real u = (x - real(2.5) * it) * real(0.8) - real(1);
+    const real u2 = u + u;
+    const real* __restrict__ c = cheb + (it * NRG + r) * (NCOEF * 2);
+    real br1 = 0, br2 = 0, bw1 = 0, bw2 = 0;
+#pragma unroll
+    for (int k = NCOEF - 1; k >= 1; k--) {
+        real t = c[2 * k] + u2 * br1 - br2; br2 = br1; br1 = t;
+        t = c[2 * k + 1] + u2 * bw1 - bw2; bw2 = bw1; bw1 = t;
+    }
+    root = (c[0] + u * br1 - br2) * tf;
+    weight = (c[1] + u * bw1 - bw2) * stf;
+}
+
+// The rows i = IE of axis_integrals_g's array (all j, k, l of that i): one phase-A1 job.  The transfer recurrence is redone per
+// job (cheap), the bra transfer and the ket transfer of the job's own rows are what is shared out.  IE is a template argument
+// (the caller switches on the job's row): every array index is a compile-time constant.  (A run-time row picked by a chain of
+// selects compiled, passed the s..f classes and raised a memory-aperture violation in (gs|gg) on the MI355X.)
+template <int IE>
+__device__ __forceinline__ void axis_row_g(real g0, real c0, real cp, real b10, real b01, real b00, real rij, real rkl,
+                                           real* __restrict__ out)
+{
+    constexpr int NA = LIJ + 2, NC = LKL + 2;
+    real t[NA][NC];
+    t[0][0] = g0;
+    t[1][0] = c0 * g0;
+#pragma unroll
+    for (int a = 1; a < NA - 1; a++) t[a + 1][0] = c0 * t[a][0] + a * b10 * t[a - 1][0];
+#pragma unroll
+    for (int c = 0; c < NC - 1; c++)
+#pragma unroll
+        for (int a = 0; a < NA; a++) {
+            real v = cp * t[a][c];
+            if (c > 0) v += c * b01 * t[a][c - 1];
+            if (a > 0) v += a * b00 * t[a - 1][c];
+            t[a][c + 1] = v;
+        }
+    // (IE, j) exists for IE + j <= LIJ + 1: no derivative raises two indices at once
+    constexpr int NJ = (LIJ + 1 - IE) < (DJ - 1) ? (LIJ + 2 - IE) : DJ;         // number of j values of this row
+    real h[NJ][NC];
+#pragma unroll
+    for (int m = 0; m < NJ; m++)
+#pragma unroll
+        for (int c = 0; c < NC; c++) h[m][c] = t[IE + m][c];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        real w[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) w[c] = h[0][c];
+#pragma unroll
+        for (int l = 0; l < DL; l++) {
+#pragma unroll
+            for (int k = 0; k < DK; k++) out[IE * SI + j * SJ + k * SK + l] = w[k];
+            if (l < DL - 1) {
+#pragma unroll
+                for (int c = 0; c < NC - 1 - l; c++) w[c] = w[c + 1] - rkl * w[c];
+            }
+        }
+        if (j < NJ - 1) {
+#pragma unroll
+            for (int m = 0; m < NJ - 1 - j; m++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) h[m][c] = h[m + 1][c] - rij * h[m][c];
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256, TWO_WG ? 2 : 1)
+KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm, const int n_dm, double* __restrict__ grad,
+      const int* __restrict__ shell_atom, const int natm, const int nrep, const real jfac, const real kfac, const real omega,
+      const ushort4* __restrict__ quartets, const unsigned* __restrict__ ntasks_ptr, const int qstride,
+      const real* __restrict__ rys_cheb, const real* __restrict__ rys_large)
+{
+    __shared__ real sExt[G][3][GSZ];                                   // extended 1-D arrays of the current (combination, root)
+    __shared__ __attribute__((aligned(32))) real sQ[G][3][GSB][4];     // derivative records of the same
+    __shared__ real sRW[G][2 * NRG];
+    __shared__ real sDkl[G][NFK * NFL];
+    __shared__ double sAcc[G][9];
+    __shared__ int s_ncomb;
+    const int tid = threadIdx.x;
+    const int slot = tid / T, lt = tid - slot * T;
+    const bool lane_on = slot < G;
+    const int sl = lane_on ? slot : 0;                                  // (idle lanes alias slot 0 for addresses only)
+    const int ci = lt / NFJ, cj = lt - ci * NFJ;
+    const long ntasks = *ntasks_ptr;
+    double* __restrict__ gout = grad + (size_t)(blockIdx.x % nrep) * natm * 3;
+    const size_t nao2 = (size_t)nao * nao;
+    const real kscale = kfac * n_dm;
+    // index bases of this lane's bra component pair inside the record arrays
+    const int bx0 = TI.x[ci] * BI + TJ.x[cj] * BJ, by0 = TI.y[ci] * BI + TJ.y[cj] * BJ, bz0 = TI.z[ci] * BI + TJ.z[cj] * BJ;
+
+    for (long base = (long)blockIdx.x * G; base < ntasks; base += (long)gridDim.x * G) {
+        const long task = base + slot;
+        bool on = lane_on && task < ntasks;
+        ushort4 sq = {0, 0, 0, 0};
+        if (on) sq = quartets[task * qstride];
+        const int ish = sq.x, jsh = sq.y, ksh = sq.z, lsh = sq.w;
+        if (ksh > ish || ish < jsh || lsh > ksh) on = false;
+        const int atom_i = shell_atom[ish], atom_j = shell_atom[jsh], atom_k = shell_atom[ksh], atom_l = shell_atom[lsh];
+        if (atom_i == atom_j && atom_i == atom_k && atom_i == atom_l) on = false;   // translational invariance: no net force
+        real fac = real(34.98683665524972497);  // 2 pi^2.5
+        if (ish == jsh) fac *= real(0.5);
+        if (ksh == lsh) fac *= real(0.5);
+        if (ish == ksh && jsh == lsh) fac *= real(0.5);
+        const real* __restrict__ bi = basis + ish * BASIS_STRIDE;
+        const real* __restrict__ bj = basis + jsh * BASIS_STRIDE;
+        const real* __restrict__ bk = basis + ksh * BASIS_STRIDE;
+        const real* __restrict__ bl = basis + lsh * BASIS_STRIDE;
+        const real rix = bi[0], riy = bi[1], riz = bi[2];
+        const real rkx = bk[0], rky = bk[1], rkz = bk[2];
+        const real rij[3] = {bj[0] - rix, bj[1] - riy, bj[2] - riz};
+        const real rkl[3] = {bl[0] - rkx, bl[1] - rky, bl[2] - rkz};
+        const real rr_ij = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2];
+        const real rr_kl = rkl[0] * rkl[0] + rkl[1] * rkl[1] + rkl[2] * rkl[2];
+        const int npi = (int)bi[10], npj = (int)bj[10], npk = (int)bk[10], npl = (int)bl[10];
+        const int i0 = (int)bi[3], j0 = (int)bj[3], k0 = (int)bk[3], l0 = (int)bl[3];
+        const int ncomb = on ? npi * npj * npk * npl : 0;
+
+        // densities of this lane: D_ij (J part, total density), its rows of the four exchange blocks (per spin)
+        real tij = 0;
+        real sik[NS_MAX][NFK], sil[NS_MAX][NFL], sjk[NS_MAX][NFK], sjl[NS_MAX][NFL];
+        for (int s = 0; s < NS_MAX; s++) {
+            const bool have = on && s < n_dm;
+            const real* __restrict__ D = dm + (have ? s : 0) * nao2;
+            if (have) tij += D[(size_t)(i0 + ci) * nao + j0 + cj];
+            for (int k = 0; k < NFK; k++) {
+                sik[s][k] = have ? kscale * D[(size_t)(i0 + ci) * nao + k0 + k] : real(0);
+                sjk[s][k] = have ? D[(size_t)(j0 + cj) * nao + k0 + k] : real(0);
+            }
+            for (int l = 0; l < NFL; l++) {
+                sil[s][l] = have ? kscale * D[(size_t)(i0 + ci) * nao + l0 + l] : real(0);
+                sjl[s][l] = have ? D[(size_t)(j0 + cj) * nao + l0 + l] : real(0);
+            }
+        }
+        tij *= real(4) * jfac;
+        __syncthreads();                               // the previous pass has left sAcc / sDkl / s_ncomb
+        if (tid == 0) s_ncomb = 0;
+        if (on) {
+            for (int n = lt; n < NFK * NFL; n += T) {
+                real v = 0;
+                for (int s = 0; s < n_dm; s++) v += dm[s * nao2 + (size_t)(k0 + n / NFL) * nao + l0 + n % NFL];
+                sDkl[sl][n] = v;
+            }
+        }
+        if (lane_on)
+            for (int n = lt; n < 9; n += T) sAcc[sl][n] = 0;
+        __syncthreads();
+        if (on && lt == 0) atomicMax(&s_ncomb, ncomb);
+        __syncthreads();
+        const int ncomb_max = s_ncomb;
+
+        real pkl[P_REGS ? NFK * NFL : 1];
+        if (P_REGS) {
+#pragma unroll
+            for (int k = 0; k < NFK; k++)
+#pragma unroll
+                for (int l = 0; l < NFL; l++) {
+                    real p = tij * sDkl[sl][k * NFL + l];
+                    for (int s = 0; s < NS_MAX; s++) p -= sik[s][k] * sjl[s][l] + sil[s][l] * sjk[s][k];
+                    pkl[k * NFL + l] = on ? p : real(0);
+                }
+        }
+        real gA[3] = {0, 0, 0}, gB[3] = {0, 0, 0}, gC[3] = {0, 0, 0};
+        for (int cmb = 0; cmb < ncomb_max; cmb++) {
+            const bool act = cmb < ncomb;
+            int c_ = act ? cmb : 0;
+            const int jp = c_ % (act ? npj : 1); c_ /= (act ? npj : 1);
+            const int ip = c_ % (act ? npi : 1); c_ /= (act ? npi : 1);
+            const int lp = c_ % (act ? npl : 1);
+            const int kp = c_ / (act ? npl : 1);
+            const real ck = bk[4 + 2 * kp], ak = bk[5 + 2 * kp];
+            const real cl = bl[4 + 2 * lp], al = bl[5 + 2 * lp];
+            const real akl = ak + al;
+            const real inv_akl = real(1) / akl;
+            const real al_akl = al * inv_akl;
+            const real ckcl = ck * cl * exp(-ak * al_akl * rr_kl);
+            const real ci_ = bi[4 + 2 * ip], ai = bi[5 + 2 * ip];
+            const real cj_ = bj[4 + 2 * jp], aj = bj[5 + 2 * jp];
+            const real aij = ai + aj;
+            const real inv_aij = real(1) / aij;
+            const real aj_aij = aj * inv_aij;
+            const real cicj = fac * ci_ * cj_ * exp(-ai * aj_aij * rr_ij);
+            const real rpa[3] = {rij[0] * aj_aij, rij[1] * aj_aij, rij[2] * aj_aij};
+            const real rqc[3] = {rkl[0] * al_akl, rkl[1] * al_akl, rkl[2] * al_akl};
+            const real rpq[3] = {rpa[0] + rix - rqc[0] - rkx, rpa[1] + riy - rqc[1] - rky, rpa[2] + riz - rqc[2] - rkz};
+            const real rr = rpq[0] * rpq[0] + rpq[1] * rpq[1] + rpq[2] * rpq[2];
+            const real inv = real(1) / (aij + akl);
+            const real theta = aij * akl * inv;
+            const real gy0 = cicj * inv_aij * inv_akl * sqrt(inv);
+            const real ai2 = ai + ai, aj2 = aj + aj, ak2 = ak + ak;
+            if (act)
+                for (int r = lt; r < NRG; r += T) {
+                    real t2, wt;
+                    rys_root_one_g(rr, theta, omega, r, rys_cheb, rys_large, t2, wt);
+                    sRW[sl][2 * r] = t2;
+                    sRW[sl][2 * r + 1] = wt;
+                }
+            __syncthreads();
+            for (int ir = 0; ir < NRG; ir++) {
+                // ---- A1: one lane per (quartet, axis, row i of the extended array)  (GRAD_A1_ROWS=0: per (quartet, axis), A/B)
+#ifndef GRAD_A1_ROWS
+#define GRAD_A1_ROWS 1
+#endif
+                constexpr int NJOB = GRAD_A1_ROWS ? 3 * DI : 3;
+                if (act)
+                    for (int job = lt; job < NJOB; job += T) {
+                        const int ax = GRAD_A1_ROWS ? job / DI : job, ie = GRAD_A1_ROWS ? job - ax * DI : 0;
+                        const real t2 = sRW[sl][2 * ir], wt = sRW[sl][2 * ir + 1];
+                        const real rt_aa = t2 * inv;
+                        const real rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
+                        const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
+                        const real b01 = real(0.5) * inv_akl * (real(1) - rt_akl);
+                        const real b00 = real(0.5) * rt_aa;
+                        const real g0 = ax == 0 ? ckcl : ax == 1 ? gy0 : wt;
+                        const real pa = ax == 0 ? rpa[0] : ax == 1 ? rpa[1] : rpa[2];
+                        const real qc = ax == 0 ? rqc[0] : ax == 1 ? rqc[1] : rqc[2];
+                        const real pq = ax == 0 ? rpq[0] : ax == 1 ? rpq[1] : rpq[2];
+                        const real dij = ax == 0 ? rij[0] : ax == 1 ? rij[1] : rij[2];
+                        const real dkl = ax == 0 ? rkl[0] : ax == 1 ? rkl[1] : rkl[2];
+#if GRAD_A1_ROWS
+                        real* __restrict__ dst = &sExt[sl][ax][0];
+                        const real c0 = pa - rt_aij * pq, cp = qc + rt_akl * pq;
+                        switch (ie) {            // DI = LI + 2 <= 6 rows
+                        case 0: axis_row_g<0>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                        case 1: axis_row_g<1>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                        case 2: if (DI > 2) axis_row_g<(DI > 2 ? 2 : 0)>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                        case 3: if (DI > 3) axis_row_g<(DI > 3 ? 3 : 0)>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                        case 4: if (DI > 4) axis_row_g<(DI > 4 ? 4 : 0)>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                        default: if (DI > 5) axis_row_g<(DI > 5 ? 5 : 0)>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                        }
+#else
+                        axis_integrals_g(g0, pa - rt_aij * pq, qc + rt_akl * pq, b10, b01, b00, dij, dkl, &sExt[sl][ax][0]);
+#endif
+                    }
+                __syncthreads();
+                // ---- A2: derivative records {g, dg/dA, dg/dB, dg/dC} of every index tuple, all lanes of the quartet
+                if (act)
+                    for (int n = lt; n < 3 * GSB; n += T) {
+                        const int ax = n / GSB, b = n - ax * GSB;
+                        const int i = b / BI, j = (b / BJ) % (LJ + 1), k = (b / BK) % (LK + 1), l = b % (LL + 1);
+                        const real* __restrict__ g = &sExt[sl][ax][i * SI + j * SJ + k * SK + l];
+                        const real g0 = g[0];
+                        const real dA = ai2 * g[SI] - (i ? i * g[-SI] : real(0));
+                        const real dB = aj2 * g[SJ] - (j ? j * g[-SJ] : real(0));
+                        const real dC = ak2 * g[SK] - (k ? k * g[-SK] : real(0));
+                        real* __restrict__ q = &sQ[sl][ax][b][0];
+                        q[0] = g0; q[1] = dA; q[2] = dB; q[3] = dC;
+                    }
+                __syncthreads();
+                // ---- B: this lane's bra component pair against every ket component
+                if (act) {
+                    const real (*__restrict__ qx)[4] = sQ[sl][0];
+                    const real (*__restrict__ qy)[4] = sQ[sl][1];
+                    const real (*__restrict__ qz)[4] = sQ[sl][2];
+                    BUNROLL
+                    for (int k = 0; k < NFK; k++)
+                    BUNROLL
+                    for (int l = 0; l < NFL; l++) {
+                        const int bx = bx0 + TK.x[k] * BK + TL.x[l];
+                        const int by = by0 + TK.y[k] * BK + TL.y[l];
+                        const int bz = bz0 + TK.z[k] * BK + TL.z[l];
+                        real p;
+                        if (P_REGS) p = pkl[k * NFL + l];
+                        else {
+                            p = tij * sDkl[sl][k * NFL + l];
+                            for (int s = 0; s < NS_MAX; s++) p -= sik[s][k] * sjl[s][l] + sil[s][l] * sjk[s][k];
+                        }
+                        const real X = qx[bx][0], Y = qy[by][0], Z = qz[bz][0];
+                        const real pyz = p * Y * Z, pxz = p * X * Z, pxy = p * X * Y;
+                        gA[0] += pyz * qx[bx][1]; gB[0] += pyz * qx[bx][2]; gC[0] += pyz * qx[bx][3];
+                        gA[1] += pxz * qy[by][1]; gB[1] += pxz * qy[by][2]; gC[1] += pxz * qy[by][3];
+                        gA[2] += pxy * qz[bz][1]; gB[2] += pxy * qz[bz][2]; gC[2] += pxy * qz[bz][3];
+                    }
+                }
+                // (the next A1 writes sExt only; its barrier separates this B from the next A2)
+            }
+        }
+        // ---- sum over the quartet's lanes in LDS, then twelve global atomics per quartet
+        if (on) {
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                atomicAdd(&sAcc[sl][x], (double)gA[x]);
+                atomicAdd(&sAcc[sl][3 + x], (double)gB[x]);
+                atomicAdd(&sAcc[sl][6 + x], (double)gC[x]);
+            }
+        }
+        __syncthreads();
+        if (on)
+            for (int n = lt; n < 12; n += T) {
+                const int c = n / 3, x = n - c * 3;
+                const double v = c < 3 ? sAcc[sl][c * 3 + x] : -(sAcc[sl][x] + sAcc[sl][3 + x] + sAcc[sl][6 + x]);
+                const int atom = c == 0 ? atom_i : c == 1 ? atom_j : c == 2 ? atom_k : atom_l;
+                atomic_add_f64(gout + atom * 3 + x, v);
+            }
+    }
+}
+#else
 extern "C" __global__ void __launch_bounds__(BLOCK)
 KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm, const int n_dm, double* __restrict__ grad,
       const int* __restrict__ shell_atom, const int natm, const int nrep, const real jfac, const real kfac, const real omega,
@@ -307,3 +662,4 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     for (long task = (long)blockIdx.x * blockDim.x + threadIdx.x; task < ntasks; task += (long)gridDim.x * blockDim.x)
         quartet_grad(nao, basis, dm, n_dm, g, shell_atom, jfac, kfac, omega, quartets[task * qstride], rys_cheb, rys_large);
 }
+#endif  // GRAD_COOP
