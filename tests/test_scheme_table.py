@@ -69,6 +69,20 @@ def test_too_many_ket_pairs_degrade_to_fewer(tmp_path, monkeypatch):
     h = router.gen_jk_kernel((2, 1, 1, 0), True, True, False, False, 0x3022, True)
     assert h >= 0
     router.gen_jk_kernel.cache_clear()
+    # the fallback is on record next to the code objects (source tag, build key, resolved variant) ...
+    tag = L.lib().jqc_source_tag().decode()
+    key = router._fallback_key((2, 1, 1, 0), True, True, False, False, 0x3022)
+    lines = [l.split() for l in open(router._fallback_file())]
+    assert [tag, key, str(0x2022)] in lines
+    # ... and the next process asks for the resolved variant at once: no compile of the variant that cannot fit
+    asked = []
+    real = L.gen_jk_kernel
+    monkeypatch.setattr(L, "gen_jk_kernel", lambda ang, dj, dk, lr, f32, algo, co=False: asked.append(algo) or real(ang, dj, dk, lr, f32, algo, co))
+    monkeypatch.setattr(router, "_fallbacks", None)            # as a fresh process: read the file again
+    router.gen_jk_kernel((2, 1, 1, 0), True, True, False, False, 0x3022, True)
+    assert asked == [0x2022]
+    assert router.resolved_algo((2, 1, 1, 0), True, True, False, False, 0x3022) == 0x2022
+    router.gen_jk_kernel.cache_clear()
 
 
 def test_builds_with_scratch_reread_their_arguments():
