@@ -326,7 +326,9 @@ constexpr int gcap(int budget) { return budget / QBYTES < 256 / T ? (budget / QB
 // (measured: the 256-register cap of two workgroups per CU pays up to a ket block of 18 components -- (fp|dp) 1 334 -> 967 ms --,
 //  larger ket blocks spill under it -- (fd|dd) 322 -> 504 ms -- and keep one workgroup with 512 registers per lane)
 constexpr bool TWO_WG = GRAD_TWO_WG && NFK * NFL <= 18 && 4 * gcap(78 * 1024) >= 3 * gcap(150 * 1024);
-constexpr bool P_REGS = NFK * NFL <= 18;         // effective density of the lane's components held in registers for the whole pass
+// effective density of the lane's components held in registers for the whole pass: up to 18 components under the 256-register cap
+// of two workgroups per CU, up to 60 with one workgroup (512 registers)
+constexpr bool P_REGS = NFK * NFL <= (TWO_WG ? 18 : 60);
 constexpr int G = TWO_WG ? gcap(78 * 1024) : gcap(150 * 1024);
 #if ((LK + 1) * (LK + 2) / 2) * ((LL + 1) * (LL + 2) / 2) <= 100
 #define BUNROLL _Pragma("unroll")          // ket loop of phase B with compile-time record offsets

@@ -103,3 +103,17 @@ def test_builds_with_scratch_reread_their_arguments():
     assert scratch > 0 and sgpr_spills <= 8
     scratch, sgpr_spills = meta("jk34_1010_j1k1_lr0_f64_*.hsaco")
     assert scratch == 0
+
+
+def test_gradient_kernel_form_is_chosen_per_class():
+    """jqc_gen_jk_grad_kernel: the cooperative form (T lanes per quartet, 1-D arrays in LDS) where it measured faster, the
+    one-quartet-per-lane form for small ket blocks (profiles/r03_grad_forms_per_class_112atoms_tzvpp.txt); g classes by ket size."""
+    if os.environ.get("JQC_GRAD_COOP") is not None:
+        pytest.skip("JQC_GRAD_COOP forces one form")
+    lib = L.lib()
+    tag = lib.jqc_grad_source_tag().decode()
+    for cls, coop in (((2, 1, 2, 1), True), ((3, 2, 2, 2), True), ((2, 1, 1, 0), False), ((1, 1, 0, 0), False),
+                      ((4, 2, 2, 2), True), ((4, 1, 1, 0), False)):
+        assert L.check(lib.jqc_gen_jk_grad_kernel(*cls, 0, 1)) >= 0
+        name = "jkgrad_%d%d%d%d_lr0%s_%s.hsaco" % (*cls, "_coop" if coop else "", tag)
+        assert os.path.exists(os.path.join(L.KERNEL_CACHE, name)), name
