@@ -424,6 +424,25 @@ def main():
             q2 = float(sum(get_jk.quartet_counts()[:2]))
             out["realistic_density"] = {"density": "C C^T / n_occ, C = rand(nao, n_occ) - 1/2, seed 9", "ms_per_step": dt2 * 1e3,
                                         "quartets_per_step": q2, "quartets_per_s": q2 / dt2}
+            # the same build with the mixed FP32 / FP64 windows of BASELINE config 4 (quartets whose bound lies between 1e-13 and
+            # 1e-7 in FP32 kernels, the rest in FP64; reference jk.py:236-248): time, share of the FP32 queue, deviation from FP64
+            try:
+                ref_j, ref_k = (x.clone() for x in get_jk(mol, dm2, hermi=1))
+                get_mixed = jkmod.generate_jk_kernel(layout, cutoff_fp64=1e-7, cutoff_fp32=1e-13)
+                vj, vk = get_mixed(mol, dm2, hermi=1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    vj, vk = get_mixed(mol, dm2, hermi=1)
+                torch.cuda.synchronize()
+                dt3 = (time.perf_counter() - t1) / 2
+                n64, n32 = get_mixed.quartet_counts()[:2]
+                out["realistic_density"]["mixed_precision"] = {
+                    "cutoff_fp64": 1e-7, "cutoff_fp32": 1e-13, "ms_per_step": dt3 * 1e3, "fp32_quartet_share": n32 / max(n64 + n32, 1),
+                    "max_rel_dev_j": float((vj - ref_j).abs().max() / ref_j.abs().max()),
+                    "max_rel_dev_k": float((vk - ref_k).abs().max() / ref_k.abs().max())}
+            except Exception as e:  # noqa: BLE001  (the headline must survive a failure of the extra leg)
+                out["realistic_density"]["mixed_precision"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_grid:
             try:
                 out["grid_path"] = grid_leg(mol)
