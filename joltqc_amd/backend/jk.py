@@ -185,7 +185,7 @@ def _known_fallbacks():
             with open(_fallback_file()) as f:
                 for line in f:
                     w = line.split()
-                    if len(w) == 3 and w[0] == tag:
+                    if len(w) == 3 and w[0] == tag and w[2].isdigit():        # (a torn or foreign line is ignored)
                         _fallbacks[w[1]] = int(w[2])
         except OSError:
             pass
