@@ -172,7 +172,9 @@ int jqc_pair_vj_launch(int handle, int nao, const double* basis_d, const double*
  * SURVEY.md 8(f) row 3.  The reference has no gradient kernels (its scanners take GPU4PySCF's CUDA gradients,
  * jqc/pyscf/__init__.py:63-97); the host-side counterpart these two calls replace is GPU4PySCF's per-atom J/K energy
  * derivative (gpu4pyscf.grad.rhf `_jk_energy_per_atom(mol, dm, vhfopt, j_factor, k_factor)`).
- * jqc_gen_jk_grad_kernel: code object of csrc/kernels/jk_grad.hip for class (li lj|lk ll), canonical order; FP64 only.
+ * jqc_gen_jk_grad_kernel: code object of csrc/kernels/jk_grad.hip for class (li lj|lk ll), canonical order; FP64 only.  The
+ *   generator picks one of two forms per class (measured table): T = nf_i nf_j lanes per quartet with the 1-D
+ *   derivative records in LDS, or one quartet per lane; jqc_jk_grad_launch sizes the grid for the form the handle was built in.
  * jqc_jk_grad_launch: for every quartet of the queue (same ushort4 entries and device-side count as jqc_jk_launch)
  *   grad_d[rep][atom][3] += d/dR_atom of  sum_abcd (ab|cd) [4 j_factor D_ab D_cd - k_factor n_dm sum_s (D^s_ac D^s_bd + D^s_ad D^s_bc)]
  *   with D = sum_s D^s, dm_d = n_dm (1 or 2) symmetric matrices [nao, nao] in the internal Cartesian order, shell_atom_d[nbas]
