@@ -64,17 +64,28 @@ def generate_get_veff():
     with ``_jqc_numpy_boundary`` -- the potential goes back as a NumPy array: PySCF adds it to ``h1e`` and contracts it with
     the density in NumPy."""
     import torch
+    from .rks import IncrementPolicy
+    policy = IncrementPolicy()
 
     def get_veff(mf, mol=None, dm=None, dm_last=None, vhf_last=None, hermi=1):
         if dm is None:
             dm = mf.make_rdm1()
         dev = _lib.require_gpu()
         as_t = lambda x: torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float64, device=dev)
-        incremental = dm_last is not None and not (np.isscalar(dm_last) and dm_last == 0) and getattr(mf, "direct_scf", True)
-        d = as_t(dm) - as_t(dm_last) if incremental else as_t(dm)
-        vj, vk = mf.get_jk(mol, d, hermi)
+        none = lambda x: x is None or (np.isscalar(x) and x == 0)
+        incremental = not none(dm_last) and not none(vhf_last) and getattr(mf, "direct_scf", True)
+        d = as_t(dm)
+        if incremental:
+            # increments as in the reference, starting over from the full density whenever the increment has shrunk by 1e3 since
+            # the last full build, and every 12 calls (rks.IncrementPolicy: the sub-cutoff terms every increment drops pile up)
+            dd = d - as_t(dm_last)
+            incremental = not policy.full_build(float(dd.abs().max()))
+        else:
+            policy.reset()
+            policy.full_build(float(d.abs().max()))
+        vj, vk = mf.get_jk(mol, dd if incremental else d, hermi)
         vhf = as_t(vj) - 0.5 * as_t(vk)
-        if vhf_last is not None and not (np.isscalar(vhf_last) and vhf_last == 0):
+        if incremental:
             vhf = vhf + as_t(vhf_last)
         if getattr(mf, "_jqc_numpy_boundary", False):
             return vhf.cpu().numpy()

@@ -105,14 +105,15 @@ def drive_grid(fn, op, which=0):
     ``which``: 0 = the object's ``grids``, 1 = its ``nlcgrids``."""
     XC = {"LDA": 1, "GGA": 4, "MGGA": 5}
 
-    def wrapped(mol, grids, xctype, mat):
+    def wrapped(mol, grids, xctype, mat, ref=None):
         import torch
         m = mat if torch.is_tensor(mat) else np.asarray(mat)
         shape = tuple(m.shape)
         if len(shape) not in (1, 2):      # checked BEFORE anything is announced: a shape the workers cannot rebuild would
             raise ValueError(f"rho_fun / vxc_fun take one matrix [n0, n1] or one vector [n1], got shape {shape}")   # desynchronise the ranks
-        _bcast_header([op, len(shape), shape[0], shape[-1], XC[xctype.upper()], which])
-        return fn(mol, grids, xctype, _bcast_matrix(m, shape))
+        # (ref: magnitude of the full matrix an increment belongs to -- rks._windows; 0 = none)
+        _bcast_header([op, len(shape), shape[0], shape[-1], XC[xctype.upper()], which, float(ref) if ref else 0.0])
+        return fn(mol, grids, xctype, _bcast_matrix(m, shape), ref)
     if hasattr(fn, "stats"):
         wrapped.stats = fn.stats
     return wrapped
@@ -174,7 +175,7 @@ def serve(handlers):
             ndim, n0, n1 = int(h[1]), int(h[2]), int(h[3])
             mat = _bcast_matrix(None, (n0, n1) if ndim == 2 else (n1,))
             fn, mol, grids = handlers[op][int(h[5])]
-            fn(mol, grids() if callable(grids) else grids, XC[int(h[4])], mat)
+            fn(mol, grids() if callable(grids) else grids, XC[int(h[4])], mat, h[6] if h[6] > 0 else None)
         elif op == OP_GRADJK:
             ndim, n_dm, nao = int(h[1]), int(h[2]), int(h[3])
             dm = _bcast_matrix(None, (n_dm, nao, nao) if ndim == 3 else (nao, nao))

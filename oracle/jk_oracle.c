@@ -323,23 +323,46 @@ double jqc_oracle_jk_bench(int nao, const double *basis, const double *dm, doubl
                 const int nfi = (li + 1) * (li + 2) / 2, nfj = (lj + 1) * (lj + 2) / 2;
                 const int nfk = (lk + 1) * (lk + 2) / 2, nfl = (ll + 1) * (ll + 2) / 2;
                 const int i0 = (int)bi[3], j0 = (int)bj[3], k0 = (int)bk[3], l0 = (int)bl[3];
-                double jij[NF_MAX * NF_MAX] = {0}, jkl[NF_MAX * NF_MAX] = {0}, kik[NF_MAX * NF_MAX] = {0};
-                double kil[NF_MAX * NF_MAX] = {0}, kjk[NF_MAX * NF_MAX] = {0}, kjl[NF_MAX * NF_MAX] = {0};
+                /* the six density sub-blocks of the quartet are gathered ONCE (nf x nf each) and the six Fock sub-blocks are
+                 * sized by the shells' own nf: no 15 x 15 zero-fill / checksum for an (ss|ss) quartet */
+                double dij[NF_MAX * NF_MAX], dkl[NF_MAX * NF_MAX], djl[NF_MAX * NF_MAX], djk[NF_MAX * NF_MAX];
+                double dil[NF_MAX * NF_MAX], dik[NF_MAX * NF_MAX];
+                double jij[NF_MAX * NF_MAX], jkl[NF_MAX * NF_MAX], kik[NF_MAX * NF_MAX];
+                double kil[NF_MAX * NF_MAX], kjk[NF_MAX * NF_MAX], kjl[NF_MAX * NF_MAX];
+                for (int a = 0; a < nfi; a++) for (int b = 0; b < nfj; b++) { dij[a * nfj + b] = dm[(i0 + a) + (long)(j0 + b) * nao]; jij[a * nfj + b] = 0; }
+                for (int a = 0; a < nfk; a++) for (int b = 0; b < nfl; b++) { dkl[a * nfl + b] = dm[(k0 + a) + (long)(l0 + b) * nao]; jkl[a * nfl + b] = 0; }
+                for (int a = 0; a < nfj; a++) for (int b = 0; b < nfl; b++) { djl[a * nfl + b] = dm[(long)(j0 + a) * nao + l0 + b]; kjl[a * nfl + b] = 0; }
+                for (int a = 0; a < nfj; a++) for (int b = 0; b < nfk; b++) { djk[a * nfk + b] = dm[(long)(j0 + a) * nao + k0 + b]; kjk[a * nfk + b] = 0; }
+                for (int a = 0; a < nfi; a++) for (int b = 0; b < nfl; b++) { dil[a * nfl + b] = dm[(long)(i0 + a) * nao + l0 + b]; kil[a * nfl + b] = 0; }
+                for (int a = 0; a < nfi; a++) for (int b = 0; b < nfk; b++) { dik[a * nfk + b] = dm[(long)(i0 + a) * nao + k0 + b]; kik[a * nfk + b] = 0; }
                 const double *e = blk;
                 for (int i = 0; i < nfi; i++)
-                for (int j = 0; j < nfj; j++)
-                for (int k = 0; k < nfk; k++)
-                for (int l = 0; l < nfl; l++, e++) {
-                    const double v = *e;
-                    const long I = i0 + i, J = j0 + j, K = k0 + k, L = l0 + l;
-                    jkl[k * NF_MAX + l] += v * dm[I + J * nao];
-                    jij[i * NF_MAX + j] += v * dm[K + L * nao];
-                    kik[i * NF_MAX + k] += v * dm[J * nao + L];
-                    kil[i * NF_MAX + l] += v * dm[J * nao + K];
-                    kjk[j * NF_MAX + k] += v * dm[I * nao + L];
-                    kjl[j * NF_MAX + l] += v * dm[I * nao + K];
+                for (int j = 0; j < nfj; j++) {
+                    double sij = 0;
+                    const double vdij = dij[i * nfj + j];
+                    for (int k = 0; k < nfk; k++) {
+                        double sik = 0, sjk = 0;
+                        const double vdjk = djk[j * nfk + k], vdik = dik[i * nfk + k];
+                        for (int l = 0; l < nfl; l++, e++) {
+                            const double v = *e;
+                            jkl[k * nfl + l] += v * vdij;
+                            sij += v * dkl[k * nfl + l];
+                            sik += v * djl[j * nfl + l];
+                            kil[i * nfl + l] += v * vdjk;
+                            sjk += v * dil[i * nfl + l];
+                            kjl[j * nfl + l] += v * vdik;
+                        }
+                        kik[i * nfk + k] += sik;
+                        kjk[j * nfk + k] += sjk;
+                    }
+                    jij[i * nfj + j] += sij;
                 }
-                for (int n = 0; n < NF_MAX * NF_MAX; n++) chk += jij[n] + jkl[n] + kik[n] + kil[n] + kjk[n] + kjl[n];
+                for (int n = 0; n < nfi * nfj; n++) chk += jij[n];
+                for (int n = 0; n < nfk * nfl; n++) chk += jkl[n];
+                for (int n = 0; n < nfi * nfk; n++) chk += kik[n];
+                for (int n = 0; n < nfi * nfl; n++) chk += kil[n];
+                for (int n = 0; n < nfj * nfk; n++) chk += kjk[n];
+                for (int n = 0; n < nfj * nfl; n++) chk += kjl[n];
             }
         }
         total += chk;

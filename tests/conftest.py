@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of the GPU suite under ``-x``: the cheap per-class oracle gates first, the full-size BASELINE configurations (minutes each,
+# whole SCF runs) last, so that one failing expensive test cannot hide the parity evidence of every other row.
+_FILE_ORDER = ["test_jk_gpu", "test_jk_pair_gpu", "test_int1e_gpu", "test_dft_gpu", "test_boundary_gpu", "test_grad_gpu",
+               "test_jk_fullsize_gpu", "test_dft_fullsize_gpu", "test_configs_gpu"]
+_HEAVY = ("112_atoms", "config3", "config4", "config5", "two_ranks")
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(item):
+        mod = item.module.__name__.rsplit(".", 1)[-1]
+        rank = _FILE_ORDER.index(mod) if mod in _FILE_ORDER else -1          # CPU files keep their place in front
+        return (any(h in item.name for h in _HEAVY) and rank >= 0, rank)
+    items.sort(key=key)                                                     # (stable: the order inside a file is kept)
+
+
 @pytest.fixture(scope="session")
 def kats():
     import json

@@ -85,7 +85,8 @@ class RHF:
         self._ovlp = ovlp
         self.direct_scf = True
         self.direct_scf_tol = 1e-13
-        self.conv_tol = 1e-10
+        self.conv_tol = 1e-9              # PySCF's defaults (scf/hf.py): |dE| < conv_tol and |orbital gradient| < conv_tol_grad
+        self.conv_tol_grad = None         # None -> sqrt(conv_tol)
         self.max_cycle = 60
         self.diis_space = 8
         self.verbose = 0
@@ -149,6 +150,16 @@ class RHF:
     # --- SCF loop -----------------------------------------------------------------------------
     _np = staticmethod(_strict)
 
+    def _converged(self, e_tot, e_last, F, c, nocc):
+        """PySCF's test (scf/hf.py kernel): |E - E_last| < conv_tol and the norm of the orbital gradient g = 2 C_occ^T F C_vir of
+        the orbitals the density was made of, divided by sqrt(its size), below conv_tol_grad (default sqrt(conv_tol))."""
+        if c is None:
+            return False
+        g = 2.0 * c[:, :nocc].T @ F @ c[:, nocc:]
+        self.norm_gorb = float(np.linalg.norm(g)) / np.sqrt(g.size)
+        tol_g = np.sqrt(self.conv_tol) if self.conv_tol_grad is None else self.conv_tol_grad
+        return abs(e_tot - e_last) < self.conv_tol and self.norm_gorb < tol_g
+
     def kernel(self, dm0=None):
         S, h = np.asarray(self._ovlp), np.asarray(self._hcore)
         s, U = np.linalg.eigh(S)
@@ -160,9 +171,10 @@ class RHF:
             e, c = np.linalg.eigh(X.T @ F @ X)
             return e, X @ c
 
+        c_cur = None                            # orbitals the current density was made of (none for a guess density)
         if dm0 is None:
-            _, c = solve(h)
-            dm = 2.0 * c[:, :nocc] @ c[:, :nocc].T
+            _, c_cur = solve(h)
+            dm = 2.0 * c_cur[:, :nocc] @ c_cur[:, :nocc].T
         else:
             dm = np.asarray(dm0)
         dm_last, vhf_last = None, None
@@ -173,6 +185,7 @@ class RHF:
             dm_last, vhf_last = dm, vhf
             F = h + vhf
             e_tot = 0.5 * float(np.einsum("ij,ji->", dm, h + F)) + enuc
+            done = self._converged(e_tot, e_last, F, c_cur, nocc)
             err = X.T @ (F @ dm @ S - S @ dm @ F) @ X
             focks.append(F)
             errs.append(err)
@@ -191,13 +204,14 @@ class RHF:
                     F = sum(wi * Fi for wi, Fi in zip(w, focks))
                 except np.linalg.LinAlgError:
                     pass
-            self.mo_energy, self.mo_coeff = solve(F)
-            dm = 2.0 * self.mo_coeff[:, :nocc] @ self.mo_coeff[:, :nocc].T
             self.cycles = it + 1
-            if abs(e_tot - e_last) < self.conv_tol and np.abs(err).max() < 1e-6:
+            if done:
                 self.converged = True
                 e_last = e_tot
                 break
+            self.mo_energy, self.mo_coeff = solve(F)
+            c_cur = self.mo_coeff
+            dm = 2.0 * c_cur[:, :nocc] @ c_cur[:, :nocc].T
             e_last = e_tot
         # final energy with the converged density
         vhf = self._np(self.get_veff(self.mol, dm, dm_last=dm_last, vhf_last=vhf_last, hermi=1))
@@ -316,6 +330,7 @@ class RKS(RHF):
         _, c = np.linalg.eigh(X.T @ h @ X)
         c = X @ c
         dm = 2.0 * c[:, :nocc] @ c[:, :nocc].T if dm0 is None else np.asarray(dm0)
+        c_cur = c if dm0 is None else None
         dm_last, v_last, e_last = 0, 0, 0.0
         errs, focks = [], []
         for it in range(self.max_cycle):
@@ -324,6 +339,10 @@ class RKS(RHF):
             F = h + self._np(veff)
             _strict(veff.vj)
             e_tot = float(np.einsum("ij,ji->", dm, h)) + float(veff.ecoul) + float(veff.exc) + enuc
+            self.cycles = it + 1
+            if self._converged(e_tot, e_last, F, c_cur, nocc):
+                self.converged = True
+                break
             err = X.T @ (F @ dm @ S - S @ dm @ F) @ X
             focks.append(F); errs.append(err)
             focks, errs = focks[-self.diis_space:], errs[-self.diis_space:]
@@ -341,11 +360,8 @@ class RKS(RHF):
                     pass
             e, cc = np.linalg.eigh(X.T @ F @ X)
             self.mo_energy, self.mo_coeff = e, X @ cc
-            dm = 2.0 * self.mo_coeff[:, :nocc] @ self.mo_coeff[:, :nocc].T
-            self.cycles = it + 1
-            if abs(e_tot - e_last) < self.conv_tol and np.abs(err).max() < 1e-6:
-                self.converged = True
-                break
+            c_cur = self.mo_coeff
+            dm = 2.0 * c_cur[:, :nocc] @ c_cur[:, :nocc].T
             e_last = e_tot
         self.e_tot = e_tot
         return e_tot

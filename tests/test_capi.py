@@ -36,3 +36,11 @@ def test_product_path_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         L.require_gpu()
+
+
+def test_reference_import_name_resolves_to_this_package():
+    """``import jqc.pyscf`` (the reference's import line, jqc/pyscf/__init__.py:20,121) gives the same three entry points."""
+    import jqc.pyscf as ref_name
+    import joltqc_amd.pyscf as own
+    assert ref_name.apply is own.apply and ref_name.get_default_config is own.get_default_config and ref_name.reset is own.reset
+    assert sorted(ref_name.__all__) == ["apply", "get_default_config", "reset"]

@@ -28,10 +28,10 @@ def _worker(rank, world, port, q):
         log.append(("jk", hermi, with_j, with_k, omega, tuple(dm.shape)))
         return (buf[0] if with_j else 0), (buf[1] if with_k else 0)
 
-    def fake_grid(mol, grids, xctype, mat):
+    def fake_grid(mol, grids, xctype, mat, ref=None):
         out = torch.as_tensor(mat, dtype=torch.float64).sum() * (rank + 1.0) * torch.ones(3, dtype=torch.float64)
         dist.all_reduce(out)
-        log.append(("grid", xctype, grids, tuple(mat.shape)))
+        log.append(("grid", xctype, grids, tuple(mat.shape), ref))
         return out
 
     def fake_sums(outer, inner, fp32):
@@ -57,7 +57,7 @@ def _worker(rank, world, port, q):
         dm3 = np.random.rand(2, 5, 5)
         vj3, vk3 = get_jk(None, dm3, hermi=0, with_j=False, omega=0.3)
         rho = par.drive_grid(fake_grid, par.OP_RHO, 0)(None, "G0", "GGA", np.ones((4, 7)))
-        vx = par.drive_grid(fake_grid, par.OP_VXC, 1)(None, "G1", "MGGA", np.ones(6))
+        vx = par.drive_grid(fake_grid, par.OP_VXC, 1)(None, "G1", "MGGA", np.ones(6), 0.25)     # (an increment: magnitude of the full matrix)
         sm = par.drive_vv10(fake_sums)(torch.arange(40, dtype=torch.float64).reshape(5, 8), torch.ones(6, 4, dtype=torch.float64), True)
         gr = par.drive_grad_jk(fake_grad)(None, dm3, j_factor=0.5, k_factor=0.25, omega=0.2)
         par.stop()
@@ -86,7 +86,7 @@ def test_driver_and_worker_mirror_every_call():
     assert isinstance(r0["vj"], np.ndarray) and np.allclose(r0["vj"], 3.0 * r0["dm"]) and np.allclose(r0["vk"], 6.0 * r0["dm"])
     assert r0["vj3"] == 0 and np.allclose(r0["vk3"], 6.0 * r0["dm3"]) and log1[1] == ("jk", 0, False, True, 0.3, (2, 5, 5))
     assert np.allclose(r0["rho"], 28.0 * 3.0) and np.allclose(r0["vx"], 6.0 * 3.0)
-    assert log1[2] == ("grid", "GGA", "G0", (4, 7)) and log1[3] == ("grid", "MGGA", "G1", (6,))
+    assert log1[2] == ("grid", "GGA", "G0", (4, 7), None) and log1[3] == ("grid", "MGGA", "G1", (6,), 0.25)
     assert np.allclose(r0["sm"], np.tile(np.arange(24, 32) * 4.0, (3, 1)))
     assert isinstance(r0["gr"], np.ndarray) and np.allclose(r0["gr"], 1.5 * r0["dm3"].sum()) and log1[-1] == ("grad", 0.5, 0.25, 0.2, (2, 5, 5))
 
