@@ -52,6 +52,10 @@ extern "C" {
 #define JQC_VARIANT_PAROOT (1 << 19) /* row-lane mode: a phase-A job = (quartet, root), three axes per job (Rys root evaluated once) */
 #define JQC_VARIANT_NDM2 (1 << 20)  /* two density matrices contracted per integral evaluation (D / Fock tiles of both in LDS); the
                                       kernel walks n_dm in pairs.  Lane-per-quartet builds and owner-reduction builds only */
+#define JQC_VARIANT_MIXED (1 << 21) /* FP64 lane-per-quartet build with BOTH precision windows in one launch: quartets with an
+                                      estimate above cut_hi in FP64, those in (cut_lo, cut_hi] in FP32, two per lane as packed
+                                      2-vectors (v_pk_fma_f32); one staging / screening / flush per tile pair (replaces the reference's
+                                      fp32 + fp64 launch pair per class, jqc/pyscf/jk.py:293-328) */
 
 const char* jqc_last_error(void);
 const char* jqc_version(void);
@@ -96,8 +100,11 @@ int jqc_jk_launch(int handle, int nao, const void* basis_d, const void* dm_d, do
  *   tpair_sh_d  uint32[...] = first shell of tile i <<16 | first shell of tile j; tpair_q_d = max log-Schwarz of the
  *               pair, each list sorted descending (a workgroup stops at the first ket pair below the cutoff)
  *   q_cond_d, log_dm_d  float[nbas*nbas];  processes quartets with cut_lo < q_ij+q_kl+d_large <= cut_hi
+ *               (JQC_VARIANT_MIXED builds: every quartet above cut_lo -- FP64 above cut_hi, FP32 in (cut_lo, cut_hi])
  *   counter_d   optional uint64[]: the number of quartets evaluated by a workgroup is added to counter_d[cnt]
  *               (per-class dispatch counters = the "ERI quartets/s" metric, reference jk.py:288-330)
+ *   counter32_d optional uint64[], JQC_VARIANT_MIXED builds: the quartets of the FP32 window go to counter32_d[cnt]
+ *               (and only the FP64 ones to counter_d); ignored by every other build
  *   blk_index_d int32[nblocks/256 + 1]: task row of every 256th workgroup (coarse index of the blk0 column)
  *   tpair_ao_d  uint32[...] = first AO of tile i <<16 | first AO of tile j (same indexing as tpair_sh_d; nao < 65536)
  *   tpair_pp_d  uint32[...] = offset (units of 27 reals) of the tile pair's block in pair_tab_d, the primitive-pair
@@ -109,7 +116,8 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
                        double omega, const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* tpair_sh_d,
                        const float* tpair_q_d, const float* q_cond_d, const float* log_dm_d, int nbas, float cut_lo,
                        float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, const int32_t* blk_index_d,
-                       const uint32_t* tpair_ao_d, const uint32_t* tpair_pp_d, const void* pair_tab_d, void* stream);
+                       const uint32_t* tpair_ao_d, const uint32_t* tpair_pp_d, const void* pair_tab_d, uint64_t* counter32_d,
+                       void* stream);
 
 /* Screening + queue generation (replaces screen_jk_tasks, jqc/backend/jk/screen_jk_tasks.cu:75-340).
  * One launch handles a whole chunk of "screen tasks"; task t covers the rectangle

@@ -53,6 +53,24 @@ def class_key(ang):
 
 
 VARIANT_ORED, VARIANT_PAROOT, VARIANT_NDM2 = 1 << 18, 1 << 19, 1 << 20     # include/jqc_hip.h
+VARIANT_MIXED = 1 << 21        # both precision windows in one launch of an FP64 lane-per-quartet build (FP32 phase packed)
+
+
+def supports_mixed(ang, v):
+    """May variant ``v`` of class ``ang`` be built with the fused FP64 + packed-FP32 compute phases (JQC_VARIANT_MIXED)?"""
+    return (v & 0xf) == _lib.ALGO_TILE1Q and not (v & VARIANT_NDM2)
+
+
+def mixed_fused(ang, v):
+    """Mixed precision of class ``ang``: ONE launch of the MIXED build of variant ``v`` (FP64 phase + packed-FP32 phase behind one
+    staging of every tile pair) instead of the fp64 kernel alone?  Measured table (gfx950_scheme.json "mixed_fused",
+    tools/mixed_class_bench.py); JQC_MIXED_FUSED=1/0 forces the answer for every class that supports the build."""
+    if not supports_mixed(ang, v):
+        return False
+    force = os.environ.get("JQC_MIXED_FUSED")
+    if force is not None:
+        return force == "1"
+    return bool(_table().get("mixed_fused", {}).get(class_key(ang), False))
 
 
 def lanes_per_quartet(ang, v):
@@ -80,8 +98,8 @@ def forced_variant(ang, v):
     if (v & 0xf) == _lib.ALGO_TILE1Q:
         v &= ~(0x30000 | VARIANT_ORED | VARIANT_PAROOT)   # integral chunks, owner reduction, per-root phase A: row-lane mode only
     if (v & 0xf) != _lib.ALGO_TILE1Q:
-        v &= ~0xf000                                  # several ket pairs per iteration, strided queue, row-ordered contraction:
-                                                      # lane-per-quartet mode only
+        v &= ~(0xf000 | VARIANT_MIXED)                # several ket pairs per iteration, strided queue, row-ordered contraction,
+                                                      # fused precision phases: lane-per-quartet mode only
     nf = lambda l: (l + 1) * (l + 2) // 2
     if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or nf(ang[0]) * nf(ang[1]) > 64):
         v &= ~0x400
@@ -223,7 +241,10 @@ def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None
             # pairs per iteration, then the plain row-lane kernel.  Anything else (compiler error, missing source) is raised.
             if not _lds_overflow(e):
                 raise
-            if (algo & VARIANT_NDM2) and (algo & 0xf) != _lib.ALGO_TILE1Q:
+            if algo & VARIANT_MIXED:
+                algo &= ~VARIANT_MIXED                # the FP32 copy of the Rys table does not fit: the caller sees the resolved
+                                                      # variant and keeps the class on its fp64 launch (pyscf/jk.py)
+            elif (algo & VARIANT_NDM2) and (algo & 0xf) != _lib.ALGO_TILE1Q:
                 algo &= ~VARIANT_NDM2                 # the tiles of two density matrices do not fit: one matrix per pass
             elif algo & 0x3000:
                 nks = (algo >> 12) & 3

@@ -63,7 +63,7 @@ def lib():
         L.jqc_gen_jk_kernel.argtypes = [i32] * 10
         L.jqc_jk_launch.argtypes = [i32, i32, vp, vp, vp, vp, f64, vp, vp, i64, i32, i32, vp]
         L.jqc_jk_tile_launch.argtypes = [i32, i32, vp, vp, vp, vp, f64, vp, i32, i32, vp, vp, vp, vp, i32, f32, f32, f32,
-                                         i32, vp, vp, vp, vp, vp, vp]
+                                         i32, vp, vp, vp, vp, vp, vp, vp]
         L.jqc_pair_table.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L.jqc_screen_jk_tasks.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp]
         L.jqc_shell_block_max.argtypes = [vp, i32, i32, vp, i32, vp, vp]

@@ -542,7 +542,7 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
     for (const char* f : {"jk_common.h", "jk_axis.h"}) h0 = mix(h0, read_file(g_src_dir + "/" + f));
     if (const char* extra = getenv("JQC_EXTRA_DEFS")) h0 = mix(h0, extra);
     // (bump when the build logic of jqc_gen_jk_kernel changes: MINW rebuild loop, ECAP codes, KARG_RELOAD choice, variant bits)
-    h0 = mix(h0, "build-policy-r3:karg-reload-iff-scratch,ored,paroot,ndm2,family-tags");
+    h0 = mix(h0, "build-policy-r4:karg-reload-iff-scratch,ored,paroot,ndm2,family-tags,mixed");
     // compiler version and option set: register allocation decides which builds pass the gates, so code
     // objects of another hiprtc are other builds -- not reused from the cache, not covered by the verified manifest
     {
@@ -603,6 +603,9 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     const int v_qil = (algo_variant >> 14) & 1, v_cord = (algo_variant >> 15) & 1;
     const int v_ecap = (algo_variant >> 16) & 3;
     const int v_ored = (algo_variant >> 18) & 1, v_paroot = (algo_variant >> 19) & 1, v_ndm2 = (algo_variant >> 20) & 1;
+    const int v_mixed = (algo_variant >> 21) & 1;
+    if (v_mixed && (algo != JQC_ALGO_TILE1Q || fp32 || v_ndm2))
+        return fail(-1, "JQC_VARIANT_MIXED: FP64 lane-per-quartet builds with one density matrix per evaluation only");
     if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
     if (!do_j && !do_k) return fail(-1, "need do_j or do_k");
@@ -616,7 +619,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     // per-class entry-point name so that rocprofv3 --stats lists every class separately
     char entry[64];
     snprintf(entry, sizeof entry, "%s_%d%d%d%d%s", tiled ? (algo == JQC_ALGO_TILE1Q ? "jk_tile1q" : algo == JQC_ALGO_TILE512 ? "jk_tile512" : "jk_tile") : "jk_1q1t",
-             li, lj, lk, ll, fp32 ? "_f32" : "");
+             li, lj, lk, ll, fp32 ? "_f32" : (v_mixed ? "_mx" : ""));
     const std::string out = g_cache_dir + "/" + key + "_" + g_src_tag + ".hsaco";
     if (!file_exists(out)) {
         std::vector<std::string> d = {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
@@ -639,6 +642,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
         if (v_ored) d.push_back("-DORED=1");
         if (v_paroot) d.push_back("-DPAROOT=1");
         if (v_ndm2) d.push_back("-DNDM=2");
+        if (v_mixed) d.push_back("-DMIXED=1");
         if (tiled) {
             // Builds that spill vector registers to scratch also re-read the staging pointers from the kernarg segment
             // (KARG_RELOAD in jk_tile.hip: ~45 fewer SGPRs spilled to VGPR lanes); builds without scratch keep the
@@ -729,7 +733,8 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
                        double omega, const int32_t* tasks_d, int ntasks, int nblocks, const uint32_t* tpair_sh_d,
                        const float* tpair_q_d, const float* q_cond_d, const float* log_dm_d, int nbas, float cut_lo,
                        float cut_hi, float log_max_dm, int n_dm, uint64_t* counter_d, const int32_t* blk_index_d,
-                       const uint32_t* tpair_ao_d, const uint32_t* tpair_pp_d, const void* pair_tab_d, void* stream)
+                       const uint32_t* tpair_ao_d, const uint32_t* tpair_pp_d, const void* pair_tab_d, uint64_t* counter32_d,
+                       void* stream)
 {
     KernelView k;
     if (!kernel_view(handle, k)) return fail(-1, "invalid kernel handle %d", handle);
@@ -747,7 +752,7 @@ int jqc_jk_tile_launch(int handle, int nao, const void* basis_d, const void* dm_
     const void* large = k.fp32 ? (const void*)rys_large32(n) : (const void*)rys_large64(n);
     void* args[] = {&nao, &basis_d, &dm_d, &vj_d, &vk_d, k.fp32 ? (void*)&omega_f : (void*)&omega, &tasks_d, &ntasks,
                     &tpair_sh_d, &tpair_q_d, &q_cond_d, &log_dm_d, &nbas, &cut_lo, &cut_hi, &log_max_dm, &n_dm,
-                    &cheb, &large, &counter_d, &blk_index_d, &tpair_ao_d, &tpair_pp_d, &pair_tab_d};
+                    &cheb, &large, &counter_d, &blk_index_d, &tpair_ao_d, &tpair_pp_d, &pair_tab_d, &counter32_d};
     const unsigned threads = k.algo == JQC_ALGO_TILE512 ? 512 : 256;
     HIP_OK(hipModuleLaunchKernel(k.fn, (unsigned)nblocks, 1, 1, threads, 1, 1, 0, (hipStream_t)stream, args, nullptr));
     return 0;

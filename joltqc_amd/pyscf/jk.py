@@ -558,16 +558,16 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                         n_launch += 1
             return len(plans)
 
-        def tile_launch(h, fp32_kernel, vj_x, vk_x, lo, hi, cnt, sp_, tab_p, ntab, nblk, idx_p):
+        def tile_launch(h, fp32_kernel, vj_x, vk_x, lo, hi, cnt, sp_, tab_p, ntab, nblk, idx_p, cnt32=None):
             tt = state["tiles"][om]
             bas, dmat = (b32, dms_fp32) if fp32_kernel else (b64, dms)
             ptab = tt.pair_tab32() if fp32_kernel else tt.pair_tab
             _lib.check(L.jqc_jk_tile_launch(h, nao, bas.data_ptr(), dmat.data_ptr(), vj_x, vk_x, om, tab_p, ntab, nblk,
                                             tt.sh.data_ptr(), tt.q.data_ptr(), tt.q_dev.data_ptr(), log_dm_cond.data_ptr(),
                                             nbas, lo, hi, log_max_dm, n_dm, cnt, idx_p, tt.ao.data_ptr(),
-                                            tt.pp_off.data_ptr(), ptab.data_ptr(), sp_))
+                                            tt.pp_off.data_ptr(), ptab.data_ptr(), cnt32, sp_))
 
-        def first_use_check(ang, algo_req, fp32_kernel, h, bucket):
+        def first_use_check(ang, algo_req, fp32_kernel, h, bucket, fused=False):
             """A tile-kernel build that is not in the verified manifest (joltqc_amd/data/verified_kernels.json: another
             variant, edited sources, another compiler) is run once against the independent one-quartet-per-lane kernel on
             this call's own inputs (whole class, unsharded); a build that disagrees raises instead of contributing to J/K."""
@@ -581,15 +581,19 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
             scratch = torch.zeros((2,) + tuple(fock.shape), dtype=torch.float64, device=dev)
             pj = lambda m: scratch[m, 0].data_ptr() if with_j else None
             pk = lambda m: scratch[m, -1].data_ptr() if with_k else None
-            tile_launch(h, fp32_kernel, pj(0), pk(0), log_cutoff_fp32, INF, None, stream, tab_d.data_ptr(), tab.shape[0], nblk,
-                        index_d.data_ptr())
             run_queue(lambda a: tuple(a) == tuple(ang), pj(1), pk(1), log_cutoff_fp32, log_cutoff_fp32, False, None, False)
             ref = float(scratch[1].abs().max().item())
-            err = float((scratch[0] - scratch[1]).abs().max().item())
-            tol = (2e-4 if fp32_kernel else 1e-9) * max(ref, 1e-300)
-            if not err <= tol:
-                raise RuntimeError(f"J/K kernel build {key} disagrees with the one-quartet-per-lane reference kernel on its "
-                                   f"first use (max |diff| {err:.3e}, largest element {ref:.3e}): the build is rejected")
+            # a fused (JQC_VARIANT_MIXED) build is checked twice: every quartet through its FP64 phase (window (cut, cut] empty),
+            # then every quartet through its packed-FP32 phase (window (cut, inf))
+            for hi, loose in (((log_cutoff_fp32, False), (INF, True)) if fused else ((INF, fp32_kernel),)):
+                scratch[0].zero_()
+                tile_launch(h, fp32_kernel, pj(0), pk(0), log_cutoff_fp32, hi, None, stream, tab_d.data_ptr(), tab.shape[0], nblk,
+                            index_d.data_ptr())
+                err = float((scratch[0] - scratch[1]).abs().max().item())
+                tol = (2e-4 if loose else 1e-9) * max(ref, 1e-300)
+                if not err <= tol:
+                    raise RuntimeError(f"J/K kernel build {key} disagrees with the one-quartet-per-lane reference kernel on its "
+                                       f"first use (max |diff| {err:.3e}, largest element {ref:.3e}): the build is rejected")
             _FIRST_USE_OK.add(key)
 
         # ---------------- tiled kernels: no queue, one launch per angular class, classes spread over streams
@@ -667,8 +671,20 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     # elsewhere the fp64 kernel takes both windows in ONE launch (more accurate and, on this chip, faster:
                     # two launches stage and screen every tile pair twice)
                     split = mixed and (fp32_only or _router.fp32_pays(ang))
-                    tile_launch(h64, False, vj_p, vk_p, log_cutoff_fp64 if split else log_cutoff_fp32, INF,
-                                tile_counts[0].data_ptr(), sp, *geo)
+                    # ... or BOTH windows in one launch of the fused build (JQC_VARIANT_MIXED: FP64 phase + packed-FP32 phase, two
+                    # quartets per lane, behind one staging / screening / flush of every tile pair)
+                    fused = mixed and not split and n_dm == 1 and _router.mixed_fused(ang, algo64)
+                    if fused:
+                        amx = algo64 | _router.VARIANT_MIXED
+                        hmx = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=amx)
+                        fused = bool(_router.resolved_algo(ang, with_j, with_k, lr, False, amx) & _router.VARIANT_MIXED)
+                    if fused:
+                        first_use_check(ang, amx, False, hmx, bucket, fused=True)
+                        tile_launch(hmx, False, vj_p, vk_p, log_cutoff_fp32, log_cutoff_fp64, tile_counts[0].data_ptr(), sp, *geo,
+                                    cnt32=tile_counts[1].data_ptr())
+                    else:
+                        tile_launch(h64, False, vj_p, vk_p, log_cutoff_fp64 if split else log_cutoff_fp32, INF,
+                                    tile_counts[0].data_ptr(), sp, *geo)
                     n_launch += 1
                     if split:
                         algo32 = _router.select_algo(ang, True)
