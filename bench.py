@@ -94,8 +94,8 @@ def sample_quartets(layout, per_class, n, rng):
 
 
 def physical_cores():
-    """Physical cores this process may run on (one OpenMP thread per core: the oracle's inner loops are FP64-FMA bound, a second
-    hardware thread per core adds nothing but cache pressure)."""
+    """Physical cores this process may run on, capped by the container's CPU quota (one OpenMP thread per core: the oracle's inner
+    loops are FP64-FMA bound, a second hardware thread per core adds nothing but cache pressure)."""
     cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     seen = set()
     for c in cpus:
@@ -104,7 +104,22 @@ def physical_cores():
                 seen.add(f.read().strip())
         except OSError:
             seen.add(str(c))
-    return max(1, len(seen))
+    n = max(1, len(seen))
+    # a container's CPU-time quota (cgroup v2 cpu.max / v1 cfs_quota): the GPU box shows 256 logical CPUs and grants 16 CPUs' worth
+    # of time -- more threads than that only time-slice (measured: 128 threads = 9.8x one thread)
+    for quota_f, period_f in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            with open(quota_f) as f:
+                w = f.read().split()
+            if period_f:
+                with open(period_f) as f:
+                    w.append(f.read().split()[0])
+            if w[0] not in ("max", "-1") and float(w[1]) > 0:
+                n = max(1, min(n, int(float(w[0]) / float(w[1]) + 0.5)))
+            break
+        except (OSError, IndexError, ValueError):
+            continue
+    return n
 
 
 def cpu_baseline(mol, layout, per_class, seconds=12.0):
@@ -157,7 +172,7 @@ def cpu_baseline(mol, layout, per_class, seconds=12.0):
             "class_mix_top": {k: round(v / len(sample), 4) for k, v in top},
             "sample": f"{len(sample)} canonical quartets drawn (before the clock starts) from this workload's dispatched "
                       f"(class, primitive pattern) histogram, {reps} passes = {done} quartets in {dt:.1f} s on {cores} OpenMP "
-                      f"threads (one per physical core), and every {max(1, cores // 2)}th of them on ONE thread for {dt1:.1f} s "
+                      f"threads (one per physical core the container's CPU quota grants), and every {max(1, cores // 2)}th of them on ONE thread for {dt1:.1f} s "
                       f"({r1:.3e} quartets/s; parallel efficiency {rn / (r1 * cores):.2f}): ERI block + six contractions per "
                       f"quartet in oracle/jk_oracle.c (gcc -O3 -mavx2 -mfma), thread-local digestion sized by the shells' nf "
                       f"(no atomics, no Python in the timed region)"}

@@ -52,6 +52,8 @@ extern "C" {
 #define JQC_VARIANT_PAROOT (1 << 19) /* row-lane mode: a phase-A job = (quartet, root), three axes per job (Rys root evaluated once) */
 #define JQC_VARIANT_NDM2 (1 << 20)  /* two density matrices contracted per integral evaluation (D / Fock tiles of both in LDS); the
                                       kernel walks n_dm in pairs.  Lane-per-quartet builds and owner-reduction builds only */
+#define JQC_VARIANT_RSPLIT(code) ((code) << 22) /* row-lane mode: the Rys roots go through phase A / phase B in code + 1 groups, so the
+                                      TRR array in LDS holds nroots / (code + 1) roots per quartet (room for a second workgroup per CU) */
 #define JQC_VARIANT_MIXED (1 << 21) /* FP64 lane-per-quartet build with BOTH precision windows in one launch: quartets with an
                                       estimate above cut_hi in FP64, those in (cut_lo, cut_hi] in FP32, two per lane as packed
                                       2-vectors (v_pk_fma_f32); one staging / screening / flush per tile pair (replaces the reference's

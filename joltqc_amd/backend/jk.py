@@ -53,12 +53,24 @@ def class_key(ang):
 
 
 VARIANT_ORED, VARIANT_PAROOT, VARIANT_NDM2 = 1 << 18, 1 << 19, 1 << 20     # include/jqc_hip.h
+VARIANT_RSPLIT = lambda code: code << 22      # row-lane mode: Rys roots in code + 1 groups through phase A / B (half the TRR array)
 VARIANT_MIXED = 1 << 21        # both precision windows in one launch of an FP64 lane-per-quartet build (FP32 phase packed)
 
 
 def supports_mixed(ang, v):
     """May variant ``v`` of class ``ang`` be built with the fused FP64 + packed-FP32 compute phases (JQC_VARIANT_MIXED)?"""
     return (v & 0xf) == _lib.ALGO_TILE1Q and not (v & VARIANT_NDM2)
+
+
+def mixed_variant(ang, v):
+    """Variant code of the fused build that goes with the fp64 variant ``v`` of class ``ang``.  JQC_MIXED_NKS_SHIFT=n (tuning):
+    2^n times the ket tile pairs per iteration of the fp64 variant (the packed phase needs twice the survivors to fill a wave)."""
+    v |= VARIANT_MIXED
+    up = int(os.environ.get("JQC_MIXED_NKS_SHIFT", "0"))
+    if up:
+        nks = min(3, ((v >> 12) & 3) + up)
+        v = (v & ~0x3000) | (nks << 12)
+    return v
 
 
 def mixed_fused(ang, v):
@@ -96,14 +108,17 @@ def forced_variant(ang, v):
     if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > TILE1Q_FORCE_MAX:
         return _lib.ALGO_TILE
     if (v & 0xf) == _lib.ALGO_TILE1Q:
-        v &= ~(0x30000 | VARIANT_ORED | VARIANT_PAROOT)   # integral chunks, owner reduction, per-root phase A: row-lane mode only
+        v &= ~(0x30000 | VARIANT_ORED | VARIANT_PAROOT | VARIANT_RSPLIT(3))   # integral chunks, owner reduction, per-root phase A,
+                                                                              # root groups: row-lane mode only
     if (v & 0xf) != _lib.ALGO_TILE1Q:
         v &= ~(0xf000 | VARIANT_MIXED)                # several ket pairs per iteration, strided queue, row-ordered contraction,
                                                       # fused precision phases: lane-per-quartet mode only
     nf = lambda l: (l + 1) * (l + 2) // 2
     if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or nf(ang[0]) * nf(ang[1]) > 64):
         v &= ~0x400
-    return v
+    # a fused mixed-precision build reads its two cutoffs differently from every other build (FP64 above cut_hi, FP32 below): it is
+    # only ever reached through mixed_variant() on the fused launch path of pyscf/jk.py, never selected as a class's kernel
+    return v & ~VARIANT_MIXED
 
 
 def select_algo(ang, fp32=False, small=False):

@@ -542,7 +542,7 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
     for (const char* f : {"jk_common.h", "jk_axis.h"}) h0 = mix(h0, read_file(g_src_dir + "/" + f));
     if (const char* extra = getenv("JQC_EXTRA_DEFS")) h0 = mix(h0, extra);
     // (bump when the build logic of jqc_gen_jk_kernel changes: MINW rebuild loop, ECAP codes, KARG_RELOAD choice, variant bits)
-    h0 = mix(h0, "build-policy-r4:karg-reload-iff-scratch,ored,paroot,ndm2,family-tags,mixed");
+    h0 = mix(h0, "build-policy-r4:karg-reload-iff-scratch,ored,paroot,ndm2,family-tags,mixed,rsplit");
     // compiler version and option set: register allocation decides which builds pass the gates, so code
     // objects of another hiprtc are other builds -- not reused from the cache, not covered by the verified manifest
     {
@@ -603,9 +603,11 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     const int v_qil = (algo_variant >> 14) & 1, v_cord = (algo_variant >> 15) & 1;
     const int v_ecap = (algo_variant >> 16) & 3;
     const int v_ored = (algo_variant >> 18) & 1, v_paroot = (algo_variant >> 19) & 1, v_ndm2 = (algo_variant >> 20) & 1;
-    const int v_mixed = (algo_variant >> 21) & 1;
+    const int v_mixed = (algo_variant >> 21) & 1, v_rsplit = (algo_variant >> 22) & 3;
     if (v_mixed && (algo != JQC_ALGO_TILE1Q || fp32 || v_ndm2))
         return fail(-1, "JQC_VARIANT_MIXED: FP64 lane-per-quartet builds with one density matrix per evaluation only");
+    if (v_rsplit && algo != JQC_ALGO_TILE && algo != JQC_ALGO_TILE512)
+        return fail(-1, "JQC_VARIANT_RSPLIT: row-lane builds only");
     if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
     if (!do_j && !do_k) return fail(-1, "need do_j or do_k");
@@ -643,6 +645,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
         if (v_paroot) d.push_back("-DPAROOT=1");
         if (v_ndm2) d.push_back("-DNDM=2");
         if (v_mixed) d.push_back("-DMIXED=1");
+        if (v_rsplit) d.push_back("-DRSPLIT=" + std::to_string(v_rsplit + 1));
         if (tiled) {
             // Builds that spill vector registers to scratch also re-read the staging pointers from the kernarg segment
             // (KARG_RELOAD in jk_tile.hip: ~45 fewer SGPRs spilled to VGPR lanes); builds without scratch keep the

@@ -39,23 +39,26 @@ constexpr int GSIZE = GS_I * (LI + 1);
 
 // 1-D integrals of one axis for one root: TRR in (a,c), HRR into j, HRR into l.
 // out[((i*(LJ+1)+j)*(LK+1)+k)*(LL+1)+l]
-__device__ __forceinline__ void axis_integrals(real g0, real c0, real cp, real b10, real b01, real b00,
-                                               real rij, real rkl, real* __restrict__ out)
+// (R: double / float, or a 2-vector of floats holding two quartets per lane: jk_tile.hip MIXED)
+template <typename R = real>
+__device__ __forceinline__ void axis_integrals(R g0, R c0, R cp, R b10, R b01, R b00,
+                                               R rij, R rkl, R* __restrict__ out)
 {
+    typedef R real;
     real t[LIJ + 1][LKL + 1];
     t[0][0] = g0;
     if (LIJ > 0) {
         t[1][0] = c0 * g0;
 #pragma unroll
-        for (int a = 1; a < LIJ; a++) t[a + 1][0] = c0 * t[a][0] + a * b10 * t[a - 1][0];
+        for (int a = 1; a < LIJ; a++) t[a + 1][0] = c0 * t[a][0] + float(a) * b10 * t[a - 1][0];
     }
 #pragma unroll
     for (int c = 0; c < LKL; c++) {
 #pragma unroll
         for (int a = 0; a <= LIJ; a++) {
             real v = cp * t[a][c];
-            if (c > 0) v += c * b01 * t[a][c - 1];
-            if (a > 0) v += a * b00 * t[a - 1][c];
+            if (c > 0) v += float(c) * b01 * t[a][c - 1];
+            if (a > 0) v += float(a) * b00 * t[a - 1][c];
             t[a][c + 1] = v;
         }
     }

@@ -79,6 +79,15 @@ constexpr int NQ = TSI * TSJ * TSK * TSL;
                     // whose bra and ket lists coincide ((ps|ps), (dp|dp), ...) 44 % of the iterations are of that kind
                     // (profiles/r02_survivor_statistics.txt).
 #endif
+#ifndef MIXED
+#define MIXED 0     // lane-per-quartet mode, FP64 build: 1 = mixed precision inside ONE launch.  A tile pair is staged and screened once;
+                    // quartets whose estimate lies above cut_hi are evaluated in FP64 (one per lane, the code below), those in
+                    // (cut_lo, cut_hi] in FP32 with TWO quartets per lane held as 2-vectors: the recurrences, the integral products
+                    // and the contractions are v_pk_mul / v_pk_add / v_pk_fma_f32, i.e. twice the FP64 rate in the register
+                    // footprint of one FP64 quartet (scalar FP32 VALU runs at the FP64 rate on gfx950).  Accumulation into the LDS
+                    // Fock tiles stays FP64 (reference: outputs are always f64, jk/1q1t.cu:49-50,455; the split into an fp32 and
+                    // an fp64 kernel launch per class is jqc/pyscf/jk.py:293-328 with the estimate of jk/screen_jk_tasks.cu:241-261).
+#endif
 #ifndef NDM
 #define NDM 1       // density matrices contracted against ONE evaluation of the integrals (1 or 2): the kernel walks the n_dm
                     // matrices of a call in groups of NDM; D and Fock tiles of a group live in LDS side by side.  Reference:
@@ -92,6 +101,11 @@ constexpr int NQ = TSI * TSJ * TSK * TSL;
                     // scratch area [value][lane] (conflict-free), summed by one OWNER lane per value, and added once per
                     // quartet with all lanes of the instruction on different addresses.  The scratch aliases the TRR array,
                     // which is dead during the contraction.
+#endif
+#ifndef RSPLIT
+#define RSPLIT 1    // row-lane mode: the Rys roots of a primitive combination go through phase A / phase B in RSPLIT groups, so the TRR
+                    // array holds NROOTS / RSPLIT roots per quartet: half the LDS of the largest array of these kernels (2121: 61 of
+                    // 100 KB), i.e. room for a second workgroup per CU
 #endif
 #ifndef PAROOT
 #define PAROOT 0    // row-lane mode: a phase-A job = (quartet, root) and runs the transfer recurrence of all three axes, so the
@@ -144,7 +158,8 @@ constexpr int CW = NFK / NCH;
 constexpr int E = EJ * CW * NFL;                     // integrals per lane and chunk: e = (cj * CW + kk) * NFL + cl
 constexpr int WI = TSI * NFI, WJ = TSJ * NFJ, WK = TSK * NFK, WL = TSL * NFL;
 constexpr int NT2 = (LIJ + 1) * (LKL + 1);
-constexpr int NJOB = G * 3 * NROOTS;                                      // phase-A jobs per step
+constexpr int NRH = (NROOTS + RSPLIT - 1) / RSPLIT;                       // roots per phase-A / phase-B pass
+constexpr int NJOB = G * 3 * NRH;                                         // phase-A jobs per pass
 // The TRR array is single-buffered.  A double-buffered schedule (phase A of the next primitive combination issued before
 // phase B of the current one, one barrier per combination; code paths under NBUF > 1 below) measured 3-8 % faster, but it
 // gives wrong J/K in a few classes ((fd|fp), several g classes) on large inputs -- found by tools/verify_scheme.py, not
@@ -155,7 +170,7 @@ constexpr int NJOB = G * 3 * NROOTS;                                      // pha
 #ifndef TPAD
 #define TPAD 0      // extra reals per quartet slot of the TRR array (bank spread of the phase-B reads across quartets)
 #endif
-constexpr int TRR_SLOT = NROOTS * 3 * NT2 + TPAD;                           // reals per quartet slot
+constexpr int TRR_SLOT = NRH * 3 * NT2 + TPAD;                              // reals per quartet slot
 constexpr bool USE_ORED = ORED && !TILE_1Q && T <= 64;
 constexpr int NBUF = (TRR_DOUBLE_BUFFER && !WSYNC && !USE_ORED && 2 * G * TRR_SLOT * (int)sizeof(real) <= ST_LDS_MAX) ? 2 : 1;
 // owner reduction (ORED): values per lane and step, scratch rows of RSTR doubles (odd: the owner lanes read column-wise)
@@ -181,6 +196,7 @@ __device__ __forceinline__ int trr_off(const int sl)
     return WMAP ? (sl / gw) * WREG + (sl % gw) * TRR_SLOT : sl * TRR_SLOT;
 }
 static_assert(!WSYNC || (T <= 64 && !TILE_1Q), "WSYNC needs a quartet to fit one wave");
+static_assert(RSPLIT == 1 || (!TILE_1Q && NBUF == 1), "RSPLIT: row-lane mode, single-buffered TRR array");
 static_assert(!CJR || !TILE_1Q, "CJR is a variant of the row-lane mode");
 static_assert(NDM == 1 || NDM == 2, "density matrices per integral evaluation");
 static_assert(NDM == 1 || ((TILE_1Q || USE_ORED) && !CTWO_ && !CORD_ && !STAGE_ALL_), "NDM > 1: lane-per-quartet or owner-reduction builds");
@@ -199,6 +215,8 @@ static_assert(TBLOCK == 256 || !TILE_1Q, "the lane-per-quartet mode uses 256 thr
 constexpr int KS_SHIFT = NKS == 1 ? 16 : NKS == 2 ? 15 : NKS == 4 ? 14 : 13;     // queue entry = candidate id | ket slot << KS_SHIFT
 static_assert(NKS == 1 || (TILE_1Q && (NKS == 2 || NKS == 4 || NKS == 8) && NQ <= (1 << KS_SHIFT)),
               "several ket pairs per iteration: lane-per-quartet mode, 16-bit queue entries");
+static_assert(!MIXED || (TILE_1Q && !FP32 && NDM == 1 && !STAGE_ALL_), "MIXED: FP64 lane-per-quartet builds, one density matrix per evaluation");
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Timing-only ablations of the lane-per-quartet mode (WRONG results; tools/ablate.py): bit 0 no Rys table gather, bit 1 no
 // LDS atomics (sums kept alive in a register), bit 2 no density reads from LDS, bit 3 no integral evaluation, bit 4 no
@@ -284,6 +302,54 @@ __device__ __forceinline__ void rys_root_one(real x, real theta, real omega, con
     weight = (c[1] + u * bw1 - bw2) * stf;
 #endif
 }
+
+#if MIXED
+// Rys root `r` of TWO quartets at once (FP32, one per vector component): same tables and branches as rys_root_one.  The table
+// row of each component is gathered separately (its own x interval); the Clenshaw recurrences run packed.  `cheb` is the FP32
+// copy of the class's table (LDS) or, for classes whose table stays in L2, the FP64 table converted on the fly.
+template <typename TAB>
+__device__ __forceinline__ void rys_root_pk(v2f x, const v2f theta, const float omega, const int r, const TAB* cheb,
+                                            const double* __restrict__ large, v2f& root, v2f& weight)
+{
+    v2f tf = {1.f, 1.f}, stf = {1.f, 1.f};
+    x *= theta;
+#if RYS_LR
+    {
+        const float w2 = omega * omega;
+        tf.x = w2 * __builtin_amdgcn_rcpf(w2 + theta.x);
+        tf.y = w2 * __builtin_amdgcn_rcpf(w2 + theta.y);
+        x *= tf;
+        stf.x = __builtin_amdgcn_sqrtf(tf.x);
+        stf.y = __builtin_amdgcn_sqrtf(tf.y);
+    }
+#endif
+    const float lim = float(5 * NROOTS + 35);
+    const bool big0 = x.x >= lim, big1 = x.y >= lim;
+    // (a component beyond the table takes the asymptotic form below; its polynomial is evaluated on interval 0 and dropped)
+    const int it0 = big0 ? 0 : (int)(x.x * 0.4f), it1 = big1 ? 0 : (int)(x.y * 0.4f);
+    const v2f u = {(x.x - 2.5f * it0) * 0.8f - 1.f, (x.y - 2.5f * it1) * 0.8f - 1.f};
+    const v2f u2 = u + u;
+    const TAB* c0 = cheb + (it0 * NROOTS + r) * (NCOEF * 2);
+    const TAB* c1 = cheb + (it1 * NROOTS + r) * (NCOEF * 2);
+    v2f br1 = {0.f, 0.f}, br2 = {0.f, 0.f}, bw1 = {0.f, 0.f}, bw2 = {0.f, 0.f};
+#pragma unroll
+    for (int k = NCOEF - 1; k >= 1; k--) {
+        const v2f cr = {(float)c0[2 * k], (float)c1[2 * k]}, cw = {(float)c0[2 * k + 1], (float)c1[2 * k + 1]};
+        v2f t = cr + u2 * br1 - br2; br2 = br1; br1 = t;
+        t = cw + u2 * bw1 - bw2; bw2 = bw1; bw1 = t;
+    }
+    {
+        const v2f cr = {(float)c0[0], (float)c1[0]}, cw = {(float)c0[1], (float)c1[1]};
+        root = (cr + u * br1 - br2) * tf;
+        weight = (cw + u * bw1 - bw2) * stf;
+    }
+    if (big0 || big1) {
+        const float lr = (float)large[2 * r], lw = (float)large[2 * r + 1];
+        if (big0) { const float isx = __builtin_amdgcn_rsqf(x.x); root.x = lr * isx * isx * tf.x; weight.x = lw * isx * stf.x; }
+        if (big1) { const float isx = __builtin_amdgcn_rsqf(x.y); root.y = lr * isx * isx * tf.y; weight.y = lw * isx * stf.y; }
+    }
+}
+#endif
 
 // Staging is split into "issue every global load" and "write LDS": all loads of a workgroup's staging step are in
 // flight together (one L2 round trip), instead of one round trip per tile as a load->store loop would cost.
@@ -423,7 +489,7 @@ struct KArgs {
     const unsigned* tpair_sh; const float* tpair_q; const float* q_cond; const float* log_dm; int nbas;
     float cut_lo, cut_hi, log_max_dm; int n_dm; const real* rys_cheb; const real* rys_large;
     unsigned long long* counter; const int* blk_index; const unsigned* tpair_ao; const unsigned* tpair_pp;
-    const real* pair_tab;
+    const real* pair_tab; unsigned long long* counter32;
 };
 __device__ __forceinline__ const KArgs AS4* kargs()
 {
@@ -438,7 +504,8 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         const float* __restrict__ log_dm, const int nbas, const float cut_lo, const float cut_hi,
         const float log_max_dm, const int n_dm, const real* __restrict__ rys_cheb, const real* __restrict__ rys_large,
         unsigned long long* __restrict__ counter, const int* __restrict__ blk_index,
-        const unsigned* __restrict__ tpair_ao, const unsigned* __restrict__ tpair_pp, const real* __restrict__ pair_tab)
+        const unsigned* __restrict__ tpair_ao, const unsigned* __restrict__ tpair_pp, const real* __restrict__ pair_tab,
+        unsigned long long* __restrict__ counter32)       // (MIXED builds: quartets evaluated in FP32, per task row; otherwise unused)
 {
     __shared__ unsigned s_nact[2];              // survivors of the current tile pair (double-buffered by iteration parity)
     // NKS ket tile pairs are staged and screened per iteration (lane-per-quartet mode only): classes with few candidates
@@ -457,6 +524,12 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     // Rys Chebyshev table of the class: every lane reads 28 coefficients of ITS OWN x-interval per root, i.e. 64
     // different cache lines per wave instruction from global memory; from LDS the same gather costs a few cycles
     __shared__ real sRys[RYS_IN_LDS ? RYS_TAB : 1];
+#if MIXED
+    __shared__ unsigned s_nact32[2];            // FP32-window survivors: appended to s_act from its END downwards
+    __shared__ float sRys32[RYS_IN_LDS ? RYS_TAB : 1];
+    constexpr int QEND = NKS * NQ;
+    unsigned nq32_done = 0;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -530,6 +603,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         for (int n = tid; n < NDM * NKS * WJ * WL; n += TBLOCK) sKjl[n] = 0;
 #endif
         if (tid < 2) s_nact[tid] = 0;
+#if MIXED
+        if (tid < 2) s_nact32[tid] = 0;
+#endif
         if (tid < (TSI + TSJ) * BASIS_STRIDE) sBas[tid] = rb;
 #pragma unroll
         for (int u = 0; u < NPB; u++)
@@ -537,7 +613,12 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         if (RYS_IN_LDS) {
 #pragma unroll
             for (int u = 0; u < NRYS; u++)
-                if (tid + u * TBLOCK < RYS_TAB) sRys[tid + u * TBLOCK] = rrys[u];
+                if (tid + u * TBLOCK < RYS_TAB) {
+                    sRys[tid + u * TBLOCK] = rrys[u];
+#if MIXED
+                    sRys32[tid + u * TBLOCK] = (float)rrys[u];
+#endif
+                }
         }
     }
     const real* cheb_tab = RYS_IN_LDS ? sRys : rys_cheb;
@@ -633,6 +714,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             asm volatile("" : "+v"(tid_s));
 #define tid tid_s
             if (tid == 0) s_nact[parity ^ 1] = 0;          // next iteration's counter (last read before this point)
+#if MIXED
+            if (tid == 0) s_nact32[parity ^ 1] = 0;
+#endif
 #if STAGE_ALL
             // ---- every global load of EVERY ket slot is issued before the first use of any of them: one L2 round trip per
             //      iteration instead of one per slot (the screening of a slot waits for its gathers, and a vmcnt wait covers
@@ -786,6 +870,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 for (int cand0 = cand_lo; cand0 < cand_hi; cand0 += TBLOCK) {
                     const int cd = cand0 + tid;
                     bool keep = false;
+#if MIXED
+                    bool keep32 = false;
+#endif
                     if (cd < cand_hi) {
                         const int a = cd % TSI, b = (cd / TSI) % TSJ, d = (cd / (TSI * TSJ)) % TSL;
                         const int c = QC(cd / (TSI * TSJ * TSL), a, b, d);
@@ -804,7 +891,12 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             sd = fmaxf(sd, log_dm[ksh * nbas + lsh]);
 #endif
                             const float dq = sq + sd;
+#if MIXED
+                            keep = dq > cut_hi;                          // FP64 phase
+                            keep32 = dq > cut_lo && dq <= cut_hi;        // FP32 phase (two quartets per lane)
+#else
                             keep = dq > cut_lo && dq <= cut_hi;
+#endif
                         }
                     }
                     const unsigned long long m = __ballot(keep);
@@ -814,6 +906,15 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         base = __builtin_amdgcn_readfirstlane(base);
                         if (keep) s_act[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(cd | (ks << KS_SHIFT));
                     }
+#if MIXED
+                    const unsigned long long m32 = __ballot(keep32);
+                    if (m32) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&s_nact32[parity], (unsigned)__popcll(m32));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (keep32) s_act[QEND - 1 - (base + __popcll(m32 & ((1ull << lane) - 1ull)))] = (unsigned short)(cd | (ks << KS_SHIFT));
+                    }
+#endif
                 }
                 // ---- write LDS
                 if (tid < (TSK + TSL) * BASIS_STRIDE) sBas[OFF_K + ks * KSTR + tid] = rb;
@@ -840,7 +941,13 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             __syncthreads();
             STAMP(5);
             const int nact = __builtin_amdgcn_readfirstlane((int)s_nact[parity]);
+#if MIXED
+            const int nact32 = __builtin_amdgcn_readfirstlane((int)s_nact32[parity]);
+            if (nact == 0 && nact32 == 0) continue;
+            if (idm == 0) nq32_done += nact32;
+#else
             if (nact == 0) continue;
+#endif
             const int npi = __builtin_amdgcn_readfirstlane((int)sBas[10]), npj = __builtin_amdgcn_readfirstlane((int)sBas[OFF_J + 10]);
             int kv0 = 0;                       // first staged ket slot (every slot of a task row has the same primitive counts)
 #pragma unroll
@@ -1243,6 +1350,225 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
                 STAMP(12);          // (diagnostic) contraction + LDS atomics of this batch
 }
+#if MIXED
+            // ---------------- FP32 phase of a MIXED build: TWO quartets per lane, every per-quartet quantity a 2-vector (component
+            //                  x = queue entry 2p, y = entry 2p + 1 of the FP32 survivors, which grow downwards from the end of
+            //                  s_act).  Same formulas, loop order and destinations as the FP64 phase above (reference
+            //                  jk/1q1t.cu:174-638); shell data, prefactors and density tiles are the FP64 LDS copies converted
+            //                  on load, the Fock tiles are FP64.  An odd survivor count leaves the y component of the last lane
+            //                  with a zero prefactor and no LDS atomics.
+#define PK2(p0, p1, n) ((v2f){(float)(p0)[n], (float)(p1)[n]})
+            // (pairs are dealt from the LAST lane downwards: the FP64 phase fills the workgroup's waves from the front, and a wave runs
+            //  the two phases one after the other -- dealt from the same end, waves 0-1 would run both and waves 2-3 neither)
+            for (int p2 = TBLOCK - 1 - tid; 2 * p2 < nact32; p2 += TBLOCK) {
+                const bool two = 2 * p2 + 1 < nact32;
+                const int qe0 = s_act[QEND - 1 - 2 * p2];
+                const int qe1 = two ? s_act[QEND - 2 - 2 * p2] : qe0;
+                int ksv[2], av[2], bv[2], cv[2], dv[2];
+                v2f fac;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int qe = h ? qe1 : qe0;
+                    ksv[h] = NKS > 1 ? qe >> KS_SHIFT : 0;
+                    const int qd = NKS > 1 ? qe & ((1 << KS_SHIFT) - 1) : qe;
+                    av[h] = qd % TSI; bv[h] = (qd / TSI) % TSJ; dv[h] = (qd / (TSI * TSJ)) % TSL;
+                    cv[h] = QC(qd / (TSI * TSJ * TSL), av[h], bv[h], dv[h]);
+                    int kshb = ksh0s[0], lshb = lsh0s[0];
+#pragma unroll
+                    for (int u = 1; u < NKS; u++)
+                        if (ksv[h] == u) { kshb = ksh0s[u]; lshb = lsh0s[u]; }
+                    const int ish = ish0 + av[h], jsh = jsh0 + bv[h], ksh = kshb + cv[h], lsh = lshb + dv[h];
+                    float f = 34.98683665524972497f;
+                    if (ish == jsh) f *= 0.5f;
+                    if (ksh == lsh) f *= 0.5f;
+                    if (ish == ksh && jsh == lsh) f *= 0.5f;
+                    if (h == 0) fac.x = f; else fac.y = two ? f : 0.f;
+                }
+                const real* bi0 = sBas + av[0] * BASIS_STRIDE, * bi1 = sBas + av[1] * BASIS_STRIDE;
+                const real* bj0 = sBas + OFF_J + bv[0] * BASIS_STRIDE, * bj1 = sBas + OFF_J + bv[1] * BASIS_STRIDE;
+                const real* bk0 = sBas + OFF_K + ksv[0] * KSTR + cv[0] * BASIS_STRIDE, * bk1 = sBas + OFF_K + ksv[1] * KSTR + cv[1] * BASIS_STRIDE;
+                const real* bl0 = sBas + OFF_L + ksv[0] * KSTR + dv[0] * BASIS_STRIDE, * bl1 = sBas + OFF_L + ksv[1] * KSTR + dv[1] * BASIS_STRIDE;
+                const real* pb0 = sPB + (av[0] * TSJ + bv[0]) * 27, * pb1 = sPB + (av[1] * TSJ + bv[1]) * 27;
+                const real* pk0 = sPK + (ksv[0] * TSK * TSL + cv[0] * TSL + dv[0]) * 27, * pk1 = sPK + (ksv[1] * TSK * TSL + cv[1] * TSL + dv[1]) * 27;
+                const v2f rix = PK2(bi0, bi1, 0), riy = PK2(bi0, bi1, 1), riz = PK2(bi0, bi1, 2);
+                const v2f rkx = PK2(bk0, bk1, 0), rky = PK2(bk0, bk1, 1), rkz = PK2(bk0, bk1, 2);
+                // (differences formed in FP64, then rounded: the shell centres are large numbers next to their distances)
+                const v2f rij[3] = {{(float)(bj0[0] - bi0[0]), (float)(bj1[0] - bi1[0])}, {(float)(bj0[1] - bi0[1]), (float)(bj1[1] - bi1[1])},
+                                    {(float)(bj0[2] - bi0[2]), (float)(bj1[2] - bi1[2])}};
+                const v2f rkl[3] = {{(float)(bl0[0] - bk0[0]), (float)(bl1[0] - bk1[0])}, {(float)(bl0[1] - bk0[1]), (float)(bl1[1] - bk1[1])},
+                                    {(float)(bl0[2] - bk0[2]), (float)(bl1[2] - bk1[2])}};
+                const v2f rik[3] = {{(float)(bi0[0] - bk0[0]), (float)(bi1[0] - bk1[0])}, {(float)(bi0[1] - bk0[1]), (float)(bi1[1] - bk1[1])},
+                                    {(float)(bi0[2] - bk0[2]), (float)(bi1[2] - bk1[2])}};
+                (void)rix; (void)riy; (void)riz; (void)rkx; (void)rky; (void)rkz;
+                v2f I[NINT];
+#pragma unroll
+                for (int n = 0; n < NINT; n++) I[n] = (v2f){0.f, 0.f};
+                const float omega_f = (float)omega;
+                for (int kp = 0; kp < npk; kp++)
+                for (int lp = 0; lp < npl; lp++) {
+                    const v2f ckcl = PK2(pk0, pk1, (kp * 3 + lp) * 3), inv_akl = PK2(pk0, pk1, (kp * 3 + lp) * 3 + 1), akl = PK2(pk0, pk1, (kp * 3 + lp) * 3 + 2);
+                    const v2f al_akl = PK2(bl0, bl1, 5 + 2 * lp) * inv_akl;
+                    for (int ip = 0; ip < npi; ip++)
+                    for (int jp = 0; jp < npj; jp++) {
+                        const v2f inv_aij = PK2(pb0, pb1, (ip * 3 + jp) * 3 + 1), aij = PK2(pb0, pb1, (ip * 3 + jp) * 3 + 2);
+                        const v2f aj_aij = PK2(bj0, bj1, 5 + 2 * jp) * inv_aij;
+                        const v2f cicj = fac * PK2(pb0, pb1, (ip * 3 + jp) * 3);
+                        const v2f rpa[3] = {rij[0] * aj_aij, rij[1] * aj_aij, rij[2] * aj_aij};
+                        const v2f rqc[3] = {rkl[0] * al_akl, rkl[1] * al_akl, rkl[2] * al_akl};
+                        const v2f rpq[3] = {rpa[0] + rik[0] - rqc[0], rpa[1] + rik[1] - rqc[1], rpa[2] + rik[2] - rqc[2]};
+                        const v2f rr = rpq[0] * rpq[0] + rpq[1] * rpq[1] + rpq[2] * rpq[2];
+                        const v2f asum = aij + akl;
+                        const v2f sinv = {__builtin_amdgcn_rsqf(asum.x), __builtin_amdgcn_rsqf(asum.y)};
+                        const v2f inv = sinv * sinv;
+                        const v2f theta = aij * akl * inv;
+                        const v2f gy0 = cicj * inv_aij * inv_akl * sinv;
+#pragma clang loop unroll(disable)
+                        for (int ir = 0; ir < NROOTS; ir++) {
+                            v2f t2, wt;
+                            if (RYS_IN_LDS) rys_root_pk(rr, theta, omega_f, ir, sRys32, rys_large, t2, wt);
+                            else rys_root_pk(rr, theta, omega_f, ir, rys_cheb, rys_large, t2, wt);
+                            const v2f rt_aa = t2 * inv;
+                            const v2f rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
+                            const v2f b10 = 0.5f * inv_aij * (1.f - rt_aij);
+                            const v2f b01 = 0.5f * inv_akl * (1.f - rt_akl);
+                            const v2f b00 = 0.5f * rt_aa;
+                            v2f gx[GSIZE], gy[GSIZE], gz[GSIZE];
+                            axis_integrals<v2f>(ckcl, rpa[0] - rt_aij * rpq[0], rqc[0] + rt_akl * rpq[0], b10, b01, b00, rij[0], rkl[0], gx);
+                            axis_integrals<v2f>(gy0, rpa[1] - rt_aij * rpq[1], rqc[1] + rt_akl * rpq[1], b10, b01, b00, rij[1], rkl[1], gy);
+                            axis_integrals<v2f>(wt, rpa[2] - rt_aij * rpq[2], rqc[2] + rt_akl * rpq[2], b10, b01, b00, rij[2], rkl[2], gz);
+#pragma unroll
+                            for (int i = 0; i < NFI; i++)
+#pragma unroll
+                            for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                            for (int k = 0; k < NFK; k++)
+#pragma unroll
+                            for (int l = 0; l < NFL; l++) {
+                                const int ax = TI.x[i] * GS_I + TJ.x[j] * GS_J + TK.x[k] * GS_K + TL.x[l];
+                                const int ay = TI.y[i] * GS_I + TJ.y[j] * GS_J + TK.y[k] * GS_K + TL.y[l];
+                                const int az = TI.z[i] * GS_I + TJ.z[j] * GS_J + TK.z[k] * GS_K + TL.z[l];
+                                I[((i * NFJ + j) * NFK + k) * NFL + l] += gx[ax] * gy[ay] * gz[az];
+                            }
+                        }
+                    }
+                }
+                // ---- contraction with the density tiles of each component's own (bra, ket slot) position
+                const int iA0 = av[0] * NFI, jA0 = bv[0] * NFJ, kA0 = cv[0] * NFK, lA0 = dv[0] * NFL;
+                const int iA1 = av[1] * NFI, jA1 = bv[1] * NFJ, kA1 = cv[1] * NFK, lA1 = dv[1] * NFL;
+#if DO_J
+                {
+                    const real* dkl0 = sDkl + ksv[0] * (WL * WK), * dkl1 = sDkl + ksv[1] * (WL * WK);
+                    double* jkl0 = sJkl + ksv[0] * (WL * WK), * jkl1 = sJkl + ksv[1] * (WL * WK);
+                    v2f jkl[NFK * NFL], dkl[NFK * NFL];
+#pragma unroll
+                    for (int k = 0; k < NFK; k++)
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) {
+                            jkl[k * NFL + l] = (v2f){0.f, 0.f};
+                            dkl[k * NFL + l] = (v2f){(float)dkl0[(lA0 + l) * WK + kA0 + k], (float)dkl1[(lA1 + l) * WK + kA1 + k]};
+                        }
+#pragma unroll
+                    for (int i = 0; i < NFI; i++)
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++) {
+                            const v2f dij = {(float)sDij[(jA0 + j) * WI + iA0 + i], (float)sDij[(jA1 + j) * WI + iA1 + i]};
+                            v2f sacc = {0.f, 0.f};
+#pragma unroll
+                            for (int n = 0; n < NFK * NFL; n++) {
+                                const v2f v = I[(i * NFJ + j) * NFK * NFL + n];
+                                sacc += v * dkl[n];
+                                jkl[n] += v * dij;
+                            }
+                            LDS_ADD(&sJij_r[(jA0 + j) * WI + iA0 + i], (double)sacc.x);
+                            if (two) LDS_ADD(&sJij_r[(jA1 + j) * WI + iA1 + i], (double)sacc.y);
+                        }
+#pragma unroll
+                    for (int k = 0; k < NFK; k++)
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) {
+                            LDS_ADD(&jkl0[(lA0 + l) * WK + kA0 + k], (double)jkl[k * NFL + l].x);
+                            if (two) LDS_ADD(&jkl1[(lA1 + l) * WK + kA1 + k], (double)jkl[k * NFL + l].y);
+                        }
+                }
+#endif
+#if DO_K
+                {
+                    const real* dik0 = sDik + ksv[0] * (WI * WK), * dik1 = sDik + ksv[1] * (WI * WK);
+                    const real* dil0 = sDil + ksv[0] * (WI * WL), * dil1 = sDil + ksv[1] * (WI * WL);
+                    const real* djk0 = sDjk + ksv[0] * (WJ * WK), * djk1 = sDjk + ksv[1] * (WJ * WK);
+                    const real* djl0 = sDjl + ksv[0] * (WJ * WL), * djl1 = sDjl + ksv[1] * (WJ * WL);
+                    double* kik0 = sKik + ksv[0] * (WI * WK), * kik1 = sKik + ksv[1] * (WI * WK);
+                    double* kil0 = sKil + ksv[0] * (WI * WL), * kil1 = sKil + ksv[1] * (WI * WL);
+                    double* kjk0 = sKjk + ksv[0] * (WJ * WK), * kjk1 = sKjk + ksv[1] * (WJ * WK);
+                    double* kjl0 = sKjl + ksv[0] * (WJ * WL), * kjl1 = sKjl + ksv[1] * (WJ * WL);
+                    v2f kjk[NFJ * NFK], kjl[NFJ * NFL], djk[NFJ * NFK], djl[NFJ * NFL];
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) {
+                            kjk[j * NFK + k] = (v2f){0.f, 0.f};
+                            djk[j * NFK + k] = (v2f){(float)djk0[(jA0 + j) * WK + kA0 + k], (float)djk1[(jA1 + j) * WK + kA1 + k]};
+                        }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) {
+                            kjl[j * NFL + l] = (v2f){0.f, 0.f};
+                            djl[j * NFL + l] = (v2f){(float)djl0[(jA0 + j) * WL + lA0 + l], (float)djl1[(jA1 + j) * WL + lA1 + l]};
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NFI; i++) {
+                        v2f kik[NFK], kil[NFL], dik[NFK], dil[NFL];
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) {
+                            kik[k] = (v2f){0.f, 0.f};
+                            dik[k] = (v2f){(float)dik0[(iA0 + i) * WK + kA0 + k], (float)dik1[(iA1 + i) * WK + kA1 + k]};
+                        }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) {
+                            kil[l] = (v2f){0.f, 0.f};
+                            dil[l] = (v2f){(float)dil0[(iA0 + i) * WL + lA0 + l], (float)dil1[(iA1 + i) * WL + lA1 + l]};
+                        }
+#pragma unroll
+                        for (int j = 0; j < NFJ; j++)
+#pragma unroll
+                            for (int k = 0; k < NFK; k++)
+#pragma unroll
+                                for (int l = 0; l < NFL; l++) {
+                                    const v2f v = I[((i * NFJ + j) * NFK + k) * NFL + l];
+                                    kik[k] += v * djl[j * NFL + l];
+                                    kil[l] += v * djk[j * NFK + k];
+                                    kjk[j * NFK + k] += v * dil[l];
+                                    kjl[j * NFL + l] += v * dik[k];
+                                }
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) {
+                            LDS_ADD(&kik0[(iA0 + i) * WK + kA0 + k], (double)kik[k].x);
+                            if (two) LDS_ADD(&kik1[(iA1 + i) * WK + kA1 + k], (double)kik[k].y);
+                        }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) {
+                            LDS_ADD(&kil0[(iA0 + i) * WL + lA0 + l], (double)kil[l].x);
+                            if (two) LDS_ADD(&kil1[(iA1 + i) * WL + lA1 + l], (double)kil[l].y);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < NFJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NFK; k++) {
+                            LDS_ADD(&kjk0[(jA0 + j) * WK + kA0 + k], (double)kjk[j * NFK + k].x);
+                            if (two) LDS_ADD(&kjk1[(jA1 + j) * WK + kA1 + k], (double)kjk[j * NFK + k].y);
+                        }
+#pragma unroll
+                        for (int l = 0; l < NFL; l++) {
+                            LDS_ADD(&kjl0[(jA0 + j) * WL + lA0 + l], (double)kjl[j * NFL + l].x);
+                            if (two) LDS_ADD(&kjl1[(jA1 + j) * WL + lA1 + l], (double)kjl[j * NFL + l].y);
+                        }
+                    }
+                }
+#endif
+            }
+#undef PK2
+#endif  // MIXED
 #if ABL & 2
             if (abl_sink == 1.2345e300) sJij[0] = abl_sink;
 #endif
@@ -1251,7 +1577,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             const int ncomb = npk * npl * npi * npj;
             const int nitem = per * ncomb;            // (step, primitive combination) pairs, flattened
             // phase A of item `m` into buffer m % NBUF
-            auto phase_a = [&](const int m) {
+            auto phase_a = [&](const int m, const int rh = 0) {
                 const int step = m / ncomb;
                 int cmb = m - step * ncomb;
                 const int jp = cmb % npj; cmb /= npj;
@@ -1261,12 +1587,14 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 real* __restrict__ buf = sT + (NBUF > 1 ? (m & 1) : 0) * (G * TRR_SLOT);
 #if PAROOT
 #if WSYNC
-                for (int job = lane; job < GW * NROOTS; job += 64) {
-                    const int sl = job / NROOTS, r = job - sl * NROOTS;
+                for (int job = lane; job < GW * NRH; job += 64) {
+                    const int sl = job / NRH, rloc = job - sl * NRH, r = rh * NRH + rloc;
                     const int sa = wave * GW + sl;
+                    if (RSPLIT > 1 && r >= NROOTS) continue;
 #else
-                for (int job = tid; job < G * NROOTS; job += TBLOCK) {
-                    const int sa = job / NROOTS, r = job - sa * NROOTS;
+                for (int job = tid; job < G * NRH; job += TBLOCK) {
+                    const int sa = job / NRH, rloc = job - sa * NRH, r = rh * NRH + rloc;
+                    if (RSPLIT > 1 && r >= NROOTS) continue;
 #endif
                     const int qa = sa * per + step;
                     if (qa >= nact) continue;
@@ -1326,7 +1654,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                 tt[q][cc + 1] = v;
                             }
                         }
-                        real* __restrict__ dst = buf + trr_off(sa) + (r * 3 + ax) * NT2;
+                        real* __restrict__ dst = buf + trr_off(sa) + (rloc * 3 + ax) * NT2;
 #pragma unroll
                         for (int q = 0; q <= LIJ; q++)
 #pragma unroll
@@ -1335,14 +1663,15 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
 #else
 #if WSYNC
-                for (int job = lane; job < GW * 3 * NROOTS; job += 64) {
-                    const int sl = job / (3 * NROOTS), rem = job - sl * (3 * NROOTS);
+                for (int job = lane; job < GW * 3 * NRH; job += 64) {
+                    const int sl = job / (3 * NRH), rem = job - sl * (3 * NRH);
                     const int sa = wave * GW + sl;
 #else
                 for (int job = tid; job < NJOB; job += TBLOCK) {
-                    const int sa = job / (3 * NROOTS), rem = job - sa * (3 * NROOTS);
+                    const int sa = job / (3 * NRH), rem = job - sa * (3 * NRH);
 #endif
-                    const int r = rem / 3, ax = rem - r * 3;
+                    const int rloc = rem / 3, ax = rem - rloc * 3, r = rh * NRH + rloc;
+                    if (RSPLIT > 1 && r >= NROOTS) continue;
                     const int qa = sa * per + step;
                     if (qa >= nact) continue;
                     const int qd = s_act[qa];
@@ -1404,7 +1733,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             tt[q][cc + 1] = v;
                         }
                     }
-                    real* __restrict__ dst = buf + trr_off(sa) + (r * 3 + ax) * NT2;
+                    real* __restrict__ dst = buf + trr_off(sa) + (rloc * 3 + ax) * NT2;
 #pragma unroll
                     for (int q = 0; q <= LIJ; q++)
 #pragma unroll
@@ -1467,10 +1796,12 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 
                     for (int cmb = 0; cmb < ncomb; cmb++, item++) {
                         STAMP(13);
+#pragma unroll
+                        for (int rh = 0; rh < RSPLIT; rh++) {
                         if (NBUF > 1) {
                             if (item + 1 < nitem) phase_a(item + 1);
                         } else {
-                            phase_a(item);
+                            phase_a(item, rh);
                             STEP_SYNC();
                         }
                         STAMP(10);
@@ -1482,7 +1813,8 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #else
 #pragma clang loop unroll(disable)
 #endif
-                            for (int r = 0; r < NROOTS; r++) {
+                            for (int r = 0; r < NRH; r++) {
+                                if (RSPLIT > 1 && rh * NRH + r >= NROOTS) break;
 #if CJR
                                 // bra HRR for every j power and the ket HRR in registers: gk[axis][j][k][l]
                                 real gk[3][LJ + 1][LK + 1][LL + 1];
@@ -1564,6 +1896,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         STAMP(11);
                         STEP_SYNC();
                         STAMP(12);
+                        }
                     }
 
                     // ---------------- contraction with the density sub-blocks.  All LDS reads and arithmetic first, every
@@ -2078,8 +2411,15 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         const KArgs AS4* ke = kargs();
         unsigned long long* cnt = ke->counter;
         if (tid == 0 && cnt && nq_done) atomicAdd(cnt + ke->tasks[row * 8 + 6], (unsigned long long)nq_done);
+#if MIXED
+        unsigned long long* cnt32 = ke->counter32;
+        if (tid == 0 && cnt32 && nq32_done) atomicAdd(cnt32 + ke->tasks[row * 8 + 6], (unsigned long long)nq32_done);
+#endif
     }
 #else
     if (tid == 0 && counter && nq_done) atomicAdd(counter + tk[6], (unsigned long long)nq_done);   // per task row (slot 6)
+#if MIXED
+    if (tid == 0 && counter32 && nq32_done) atomicAdd(counter32 + tk[6], (unsigned long long)nq32_done);
+#endif
 #endif
 }

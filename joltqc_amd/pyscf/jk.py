@@ -675,7 +675,7 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     # quartets per lane, behind one staging / screening / flush of every tile pair)
                     fused = mixed and not split and n_dm == 1 and _router.mixed_fused(ang, algo64)
                     if fused:
-                        amx = algo64 | _router.VARIANT_MIXED
+                        amx = _router.mixed_variant(ang, algo64)
                         hmx = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=amx)
                         fused = bool(_router.resolved_algo(ang, with_j, with_k, lr, False, amx) & _router.VARIANT_MIXED)
                     if fused:

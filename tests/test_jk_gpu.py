@@ -189,16 +189,19 @@ def test_ket_chunks_and_workgroup_splits(monkeypatch):
 
 
 ORED, PAROOT, NDM2 = 1 << 18, 1 << 19, 1 << 20        # include/jqc_hip.h (round 3: owner reduction, per-root phase A, two DMs)
+RSPLIT = lambda code: code << 22                      # (round 4: Rys roots in code + 1 groups through phase A / phase B)
 
 
 @pytest.mark.parametrize("variant", [0x21, 0x21 | 0x100, 0x21 | 0x400, 0x21 | 0x100 | 0x400, 0x22, 0x32, 0x21 | 0x800,
                                      0x21 | 0x100 | 0x800, 0x1022, 0x2022, 0x3022,
                                      0x921 | ORED, 0x921 | ORED | PAROOT, 0xd21 | ORED | PAROOT, 0x521 | ORED, 0x421 | ORED | PAROOT,
-                                     0x30521 | ORED, 0x21 | ORED, 0x10d21 | ORED | PAROOT])
+                                     0x30521 | ORED, 0x21 | ORED, 0x10d21 | ORED | PAROOT,
+                                     0xd21 | ORED | RSPLIT(1), 0xd21 | ORED | RSPLIT(2), 0x521 | ORED | RSPLIT(1), 0x121 | ORED | RSPLIT(1),
+                                     0xd21 | ORED | PAROOT | RSPLIT(1)])
 def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
     """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
     L2 | single TRR buffer | wave-local steps | j in registers | 2, 4, 8 ket pairs per iteration | owner reduction | per-root
-    phase A | integral-chunk caps; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.
+    phase A | integral-chunk caps | root groups; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.
     Role of the reference's 1q1t == 1qnt cross-check (jqc/backend/data/generate_fragment.py:278-309)."""
     from joltqc_amd.backend import jk as router
     from oracle import dense
@@ -286,7 +289,8 @@ def test_two_ranks_share_the_quartets_and_allreduce_the_fock_matrix():
     assert min(res[0][3], res[1][3]) > 0.25 * n_all
 
 
-@pytest.mark.parametrize("mode", ["jk", "j", "k", "lr", "fp32", "k_lr", "fp32_lr", "jk_main", "k_lr_main", "jk_2dm", "jk_2dm_main"])
+@pytest.mark.parametrize("mode", ["jk", "j", "k", "lr", "fp32", "k_lr", "fp32_lr", "jk_main", "k_lr_main", "jk_2dm", "jk_2dm_main",
+                                  "fused", "fused_main", "fused32", "fused_lr"])
 def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     """All 140 angular classes s..g, CLASS BY CLASS: the kernel the scheme table selects for the class vs the CPU oracle
     restricted to the quartets of that class (three atoms, artificial s/p/d/f/g basis, the reference autotuner's kind of
@@ -294,7 +298,10 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     J only, K only, long-range (omega = 0.3) and fp32, plus the long-range K-only build the RKS ``get_veff`` asks for
     with range-separated hybrids and the long-range fp32 build.  Launches of this size take the small-launch scheme
     table ("fp64_small"); the ``*_main`` modes force the main table (tuned on 112 atoms) with long ket chunks.
-    A miscompiled or racy class kernel shows up here even when the common molecules never reach it ((gg|fp) did)."""
+    A miscompiled or racy class kernel shows up here even when the common molecules never reach it ((gg|fp) did).
+    ``fused*``: the mixed-precision builds of the lane-per-quartet classes (JQC_VARIANT_MIXED: FP64 phase + packed-FP32 phase, two
+    quartets per lane, in ONE launch; reference: an fp32 and an fp64 launch per class, jqc/pyscf/jk.py:293-328) forced on --
+    ``fused``: windows 1e-13 / 30, both phases populated; ``fused32``: every quartet through the packed-FP32 phase."""
     import os
     from joltqc_amd.pyscf import jk as jkmod
     from oracle import dense
@@ -315,7 +322,12 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     with_j, with_k = mode not in ("k", "k_lr"), mode != "j"
     omega = 0.3 if mode.endswith("lr") else None
     cut64, tol = (1e100, 2e-5) if mode.startswith("fp32") else (1e-13, 1e-11)      # fp32: every quartet through the fp32 kernels
-    bad, nclass = [], 0
+    fused = mode.startswith("fused")
+    if fused:
+        monkeypatch.setenv("JQC_MIXED_FUSED", "1")
+        # (three atoms 2-3 Bohr apart and a density of O(10) elements: the estimates Q_ij Q_kl |D| of this system lie around 1e0 - 1e2)
+        cut64, tol = (1e20, 2e-5) if mode == "fused32" else (30.0, 2e-5)
+    bad, nclass, nfused, nboth = [], 0, 0, 0
     try:
         for li in range(5):
             for lj in range(li + 1):
@@ -333,6 +345,8 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
                         sc = max(np.abs(rj).max() if with_j else 0.0, np.abs(rk).max() if with_k else 0.0)
                         err = max(np.abs(_np(vj) - rj).max() if with_j else 0.0, np.abs(_np(vk) - rk).max() if with_k else 0.0) / sc
                         n64, n32, _ = get_jk.quartet_counts()
+                        nfused += n32 > 0
+                        nboth += n32 > 0 and n64 > 0
                         if not err < tol or n64 + n32 != int(sel.sum()):
                             bad.append((key, err, n64 + n32, int(sel.sum())))
                         if two_dm:          # the second matrix must not be a copy of the first one's result
@@ -342,6 +356,8 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     finally:
         os.environ.pop("JQC_ONLY_CLASS", None)
     assert nclass == 140 and not bad, bad
+    if fused:                   # the packed-FP32 phase did run in the lane-per-quartet classes (46 of the 140 in the main table)
+        assert nfused >= 25 and (mode != "fused" or nboth >= 10), (nfused, nboth)        # (measured: 29-30 classes; both phases in 12)
 
 
 @pytest.mark.parametrize("cart", [False, True])

@@ -117,3 +117,32 @@ def test_gradient_kernel_form_is_chosen_per_class():
         assert L.check(lib.jqc_gen_jk_grad_kernel(*cls, 0, 1)) >= 0
         name = "jkgrad_%d%d%d%d_lr0%s_%s.hsaco" % (*cls, "_coop" if coop else "", tag)
         assert os.path.exists(os.path.join(L.KERNEL_CACHE, name)), name
+
+
+def test_risky_builds_are_gated_twice_or_quarantined():
+    """Quarantine rule of the verified manifest (tools/make_manifest.py, tools/risky_builds_gate.py): a build with
+    more than 256 registers per lane AND SGPRs spilled to VGPR lanes -- the family of the wrong-result builds of rounds 1-3 -- may
+    only be listed as verified with a record of the forced-ket-chunk gate run TWICE on an MI355X for the same source tag: run-to-run
+    agreement <= 1e-12, agreement with the plain reference variant <= 1e-10 (2e-4 for an FP32 build)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import risky_builds_gate as RG
+    assert RG.is_risky(290, 65) and RG.is_risky(512, 1)
+    assert not RG.is_risky(256, 70) and not RG.is_risky(400, 0)
+    assert RG.parse_key("jk789793_2121_j1k1_lr0_f64_t8.4.4.2.1") == (789793, (2, 1, 2, 1), 1, 1, 0, False)
+    data = os.path.join(ROOT, "joltqc_amd", "data")
+    man = json.load(open(os.path.join(data, "verified_kernels.json")))
+    if "risky" not in man:
+        pytest.skip("manifest written before the quarantine rule")
+    gate = json.load(open(os.path.join(data, "risky_builds_gate.json")))
+    assert gate["src_tag"] == man["src_tag"]
+    listed = set(man["keys"])
+    assert not listed & set(man["quarantined"])
+    for key in man["risky"]:
+        if key in listed:
+            r = gate["results"][key]
+            loose = key.split("_")[4] == "f32" or r.get("fp32_phase")
+            assert r["ok"] and r["run_to_run"] <= 1e-12 and r["vs_ref"] <= (2e-4 if loose else 1e-10), (key, r)
+        else:
+            assert key in man["quarantined"], key

@@ -37,6 +37,13 @@ ORED_SET = sorted({0x21, 0x121, 0x421, 0x521, 0x921, 0x10421, 0x10521, 0x10321, 
                   {1 | MINW(2) | ORED | p | w | c for p in (0, PAROOT) for w in (0, WSYNC) for c in (0, CJR)})
 if os.environ.get("JQC_TUNE_SET") == "ored":
     CANDIDATES = ORED_SET
+# round 4: Rys roots in groups through phase A / phase B (RSPLIT: half / a third / a quarter of the TRR array in LDS -> a second
+# workgroup per CU where the array was what kept it out).  JQC_TUNE_SET=rsplit: the owner-reduction forms of the table x root groups
+RS = lambda code: code << 22
+RSPLIT_SET = sorted({b | RS(c) for b in (0xc0d21, 0x40d21, 0xc0521, 0x40521, 0xc0921, 0x40921, 0xc0c21, 0x40c21, 0x40121, 0xc0121)
+                     for c in (0, 1, 2, 3)} | {0x921 | RS(1), 0x521 | RS(1), 0x121 | RS(1)})
+if os.environ.get("JQC_TUNE_SET") == "rsplit":
+    CANDIDATES = RSPLIT_SET
 if os.environ.get("JQC_TUNE_ONLY"):
     CANDIDATES = [int(x, 0) for x in os.environ["JQC_TUNE_ONLY"].split(",")]
 MAX_1Q = 200
