@@ -183,7 +183,7 @@ def _rank_worker(rank, world, port, q):
     n64 = g.quartet_counts()[0]
     if rank == 0:
         torch.save((vj.cpu(), vk.cpu()), os.path.join("/tmp", f"jqc_cfg5_{port}.pt"))
-    q.put((rank, n64, time.time() - t))
+    q.put((rank, n64, time.time() - t, [float(x) for x in jkmod.build_tile_plan.last_predicted_load]))
     dist.destroy_process_group()
 
 
@@ -237,7 +237,11 @@ def test_config5_425_atoms_svp_one_rank_and_two_ranks():
     os.remove(path)
     assert float((sj.cuda() - vj).abs().max()) < 1e-11 * sc and float((sk.cuda() - vk).abs().max()) < 1e-11 * sc
     assert res[0][1] + res[1][1] == n_all                       # every dispatched quartet on exactly one rank
-    assert min(res[0][1], res[1][1]) > 0.4 * n_all              # balanced to 60 / 40 or better
+    # the split balances predicted TIME (measured ns per quartet of every class, gfx950_scheme.json), not quartet counts: an
+    # (ss|ss) quartet costs 0.05 ns, a (dd|dd) one 5 ns
+    load = res[0][3]
+    assert max(load) < 1.10 * (sum(load) / len(load)), load
+    assert min(res[0][1], res[1][1]) > 0.25 * n_all
 
 
 def _mol112(basis):
