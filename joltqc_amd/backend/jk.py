@@ -226,7 +226,9 @@ def _known_fallbacks():
 
 
 def _fallback_key(ang, do_j, do_k, rys_lr, fp32, want):
-    return "%d%d%d%d:%d%d%d%d:%d" % (*ang, bool(do_j), bool(do_k), bool(rys_lr), bool(fp32), want)
+    from ..constants import TILE_WIDTHS          # (other tile widths = other LDS footprints: part of the key, as in kernel_key)
+    return "%d%d%d%d:%d%d%d%d:%d:t%s" % (*ang, bool(do_j), bool(do_k), bool(rys_lr), bool(fp32), want,
+                                          ".".join(str(int(w)) for w in TILE_WIDTHS))
 
 
 @lru_cache(maxsize=None)
@@ -265,7 +267,9 @@ def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None
                 nks = (algo >> 12) & 3
                 algo = (algo & ~0x3000) | ((nks - 1) << 12)
             elif algo & VARIANT_NDM2:
-                algo &= ~VARIANT_NDM2
+                # two matrices do not fit even with one ket pair per iteration: one matrix per pass, with the ket pairs per
+                # iteration the variant was tuned for (not the 1 the steps above ended on)
+                algo = (algo & ~VARIANT_NDM2 & ~0x3000) | (want & 0x3000)
             elif (algo & 0xf) != _lib.ALGO_TILE or (algo & 0xc00):
                 algo = _lib.ALGO_TILE | (algo & 0x1f0)
             else:

@@ -106,6 +106,17 @@ def purge_stale_cache():
         if stem.endswith(".hsaco") and not any(stem.endswith("_" + t + ".hsaco") for t in (tag, gtag, ptag)):
             os.remove(os.path.join(KERNEL_CACHE, f))
             n += 1
+    # the record of LDS-overflow fallbacks next to the code objects (backend/jk.py) is append-only: drop the lines of other source tags
+    fb = os.path.join(KERNEL_CACHE, "lds_fallbacks.txt")
+    try:
+        with open(fb) as f:
+            lines = f.readlines()
+        keep = [ln for ln in lines if ln.split()[:1] == [tag]]
+        if len(keep) != len(lines):
+            with open(fb, "w") as f:
+                f.writelines(keep)
+    except OSError:
+        pass
     return n
 
 

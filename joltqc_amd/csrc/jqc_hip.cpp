@@ -31,6 +31,8 @@ thread_local std::string g_err;
 std::mutex g_mu;
 std::string g_src_dir, g_cache_dir;
 int g_tsw[5] = {8, 4, 4, 2, 1};     // shells per tile edge by angular momentum (jqc_set_tile_widths)
+double* g_vv10_scratch = nullptr;      // per-share partial sums of the split VV10 inner loop (jqc_vv10)
+size_t g_vv10_scratch_n = 0;
 std::string g_src_tag = "nosrc";   // FNV-1a of every kernel source: stale code objects are never reused
 std::string g_pair_tag = "nosrc";  // pair-based J kernels (pair_vj.hip + common headers)
 std::string g_grad_tag = "nosrc";  // same for the gradient kernels (jk_grad.hip + the headers it includes), kept apart so that
@@ -1161,18 +1163,30 @@ int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, co
         nsplit = std::max(1, std::min(nsplit, njb));
         const int jchunk = ((njb + nsplit - 1) / nsplit) * NG;
         nsplit = (vvngrids + jchunk - 1) / jchunk;
+        // nsplit > 1: every share writes its partial F, U, W to a scratch [share][3][ngrids] (at most ~50 MB: nsplit x ngrids stays
+        // near 2048 x pk x 256 points) and vv10_reduce_shares adds the shares in order -- no atomics, bitwise reproducible sums
+        double* out_d = F_d;
         if (nsplit > 1) {
-            HIP_OK(hipMemsetAsync(F_d, 0, sizeof(double) * ngrids, (hipStream_t)stream));
-            HIP_OK(hipMemsetAsync(U_d, 0, sizeof(double) * ngrids, (hipStream_t)stream));
-            HIP_OK(hipMemsetAsync(W_d, 0, sizeof(double) * ngrids, (hipStream_t)stream));
+            std::lock_guard<std::mutex> lk(g_mu);
+            const size_t need = (size_t)nsplit * 3 * ngrids;
+            if (g_vv10_scratch_n < need) {
+                if (g_vv10_scratch) (void)hipFree(g_vv10_scratch);
+                g_vv10_scratch = nullptr; g_vv10_scratch_n = 0;
+                HIP_OK(hipMalloc((void**)&g_vv10_scratch, need * sizeof(double)));
+                g_vv10_scratch_n = need;
+            }
+            out_d = g_vv10_scratch;
         }
-#define VV10_PK(N, C) hipLaunchKernelGGL((vv10_kernel_pk<N, C>), dim3(nwg, nsplit), dim3(256), 0, (hipStream_t)stream, F_d, U_d, \
+#define VV10_PK(N, C) hipLaunchKernelGGL((vv10_kernel_pk<N, C>), dim3(nwg, nsplit), dim3(256), 0, (hipStream_t)stream, out_d, U_d, \
                                         W_d, vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids, jchunk)
         const bool check = !(fp32 & 2);             // fp32 = 3: the denominator test cannot fail (include/jqc_hip.h)
         if (pk == 8) { if (check) VV10_PK(8, true); else VV10_PK(8, false); }
         else if (pk == 4) { if (check) VV10_PK(4, true); else VV10_PK(4, false); }
         else { if (check) VV10_PK(2, true); else VV10_PK(2, false); }
 #undef VV10_PK
+        if (nsplit > 1)
+            hipLaunchKernelGGL(vv10_reduce_shares, dim3((ngrids + 255) / 256), dim3(256), 0, (hipStream_t)stream, out_d, nsplit, ngrids,
+                               F_d, U_d, W_d);
     }
     else if (fp32 && nout == 2)
         hipLaunchKernelGGL((vv10_kernel_n<float, 2>), dim3((nb + 1) / 2), dim3(256), 0, (hipStream_t)stream, F_d, U_d, W_d,

@@ -352,8 +352,9 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
                         rows.append((tt.offset[gi, gj] + s0, n_ij, tt.offset[gk, gl], n_kl,
                                      (int(gkey[gi, 1]), int(gkey[gj, 1]), int(gkey[gk, 1]), int(gkey[gl, 1]))))
     if world > 1:
-        build_tile_plan.last_predicted_load = _shard_assign(per_class, world)[1]     # ns per rank (diagnostics, tests)
-        per_class = _shard_rows(per_class, rank, world)
+        owner, load = _shard_assign(per_class, world)          # (one O(rows x world) pass per plan)
+        build_tile_plan.last_predicted_load = load             # ns per rank (diagnostics, tests)
+        per_class = _shard_rows(per_class, rank, world, owner)
     plans = {}
     for ang, rows in per_class.items():
         if not rows:
@@ -427,9 +428,10 @@ def _shard_assign(per_class, world):
     return owner, load
 
 
-def _shard_rows(per_class, rank, world):
+def _shard_rows(per_class, rank, world, owner=None):
     """This rank's share of the task rows (every rank evaluates the same assignment, ``_shard_assign``)."""
-    owner, _ = _shard_assign(per_class, world)
+    if owner is None:
+        owner, _ = _shard_assign(per_class, world)
     mine = {}
     for a, rows in per_class.items():
         keep = [r for r, o in zip(rows, owner[a]) if o == rank]

@@ -290,7 +290,7 @@ def test_two_ranks_share_the_quartets_and_allreduce_the_fock_matrix():
 
 
 @pytest.mark.parametrize("mode", ["jk", "j", "k", "lr", "fp32", "k_lr", "fp32_lr", "jk_main", "k_lr_main", "jk_2dm", "jk_2dm_main",
-                                  "fused", "fused_main", "fused32", "fused_lr"])
+                                  "jk_3dm", "fused", "fused_main", "fused32", "fused_lr"])
 def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     """All 140 angular classes s..g, CLASS BY CLASS: the kernel the scheme table selects for the class vs the CPU oracle
     restricted to the quartets of that class (three atoms, artificial s/p/d/f/g basis, the reference autotuner's kind of
@@ -315,10 +315,12 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     if main:
         monkeypatch.setattr(jkmod, "TARGET_WGS", 1)        # no launch counts as small; ket chunks up to KCHUNK_MAX
         mode = mode[:-5]
-    two_dm = mode == "jk_2dm"          # two density matrices in one call: the NDM = 2 builds (both contracted against ONE
-    if two_dm:                         # evaluation of the integrals, reference jk/1q1t.cu:423-638)
+    two_dm = mode in ("jk_2dm", "jk_3dm")  # several density matrices in one call: the NDM = 2 builds (a pair contracted against ONE
+    if two_dm:                         # evaluation of the integrals, reference jk/1q1t.cu:423-638); three = a pair + the odd tail
+        dm = np.stack([dm, _dm(mol.nao)[::-1, ::-1].copy() * 0.5 + 0.1 * np.eye(mol.nao)] +
+                      ([_dm(mol.nao).T[::-1].copy() * 0.25 + 0.2 * np.eye(mol.nao)] if mode == "jk_3dm" else []))
+        dm = 0.5 * (dm + dm.transpose(0, 2, 1))
         mode = "jk"
-        dm = np.stack([dm, _dm(mol.nao)[::-1, ::-1].copy() * 0.5 + 0.1 * np.eye(mol.nao)])
     with_j, with_k = mode not in ("k", "k_lr"), mode != "j"
     omega = 0.3 if mode.endswith("lr") else None
     cut64, tol = (1e100, 2e-5) if mode.startswith("fp32") else (1e-13, 1e-11)      # fp32: every quartet through the fp32 kernels
@@ -349,10 +351,11 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
                         nboth += n32 > 0 and n64 > 0
                         if not err < tol or n64 + n32 != int(sel.sum()):
                             bad.append((key, err, n64 + n32, int(sel.sum())))
-                        if two_dm:          # the second matrix must not be a copy of the first one's result
-                            e2 = np.abs(_np(vk)[1] - rk[1]).max() / max(np.abs(rk[1]).max(), 1e-300)
-                            if not e2 < tol:
-                                bad.append((key, "dm2", e2))
+                        if two_dm:          # every further matrix must not be a copy of the first one's result
+                            for m in range(1, dm.shape[0]):
+                                e2 = np.abs(_np(vk)[m] - rk[m]).max() / max(np.abs(rk[m]).max(), 1e-300)
+                                if not e2 < tol:
+                                    bad.append((key, "dm%d" % (m + 1), e2))
     finally:
         os.environ.pop("JQC_ONLY_CLASS", None)
     assert nclass == 140 and not bad, bad
