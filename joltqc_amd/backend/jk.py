@@ -31,6 +31,16 @@ def fp32_pays(ang):
     return bool(_table().get("fp32_pays", {}).get(class_key(ang), False))    # unmeasured classes (g): one fp64 launch
 
 
+def fp32_tile_split(ang):
+    """Mixed precision of class ``ang`` by TILE PAIRS: do the tile pairs whose bound is at or below cutoff_fp64 go to the class's
+    FP32 kernel (pyscf/jk.py build_tile_plan; each tile pair is staged by ONE of the two launches)?  Measured table
+    (gfx950_scheme.json "fp32_tile_split", tools/mixed_bench.py per class); JQC_FP32_TILE_SPLIT=1/0 forces the answer."""
+    force = os.environ.get("JQC_FP32_TILE_SPLIT")
+    if force is not None:
+        return force == "1"
+    return bool(_table().get("fp32_tile_split", {}).get(class_key(ang), False))
+
+
 def class_cost_table():
     """{class key: measured ns per dispatched quartet} (gfx950_scheme.json, tools/class_profile.py)."""
     return _table().get("ns_per_quartet", {})

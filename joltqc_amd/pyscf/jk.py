@@ -15,6 +15,7 @@ What is organised differently for MI355X (HIP streams instead of one blocking D2
   * The single host read per call is ``log_max_dm`` (the reference does the same, jk.py:183).
 """
 import math
+import os
 import time
 from typing import Dict, List, Tuple
 
@@ -83,7 +84,14 @@ def generate_get_veff():
         else:
             policy.reset()
             policy.full_build(float(d.abs().max()))
-        vj, vk = mf.get_jk(mol, dd if incremental else d, hermi)
+        announce = getattr(mf.get_jk, "set_increment_of", None)
+        if announce and incremental:
+            announce(float(d.abs().max()))
+        try:
+            vj, vk = mf.get_jk(mol, dd if incremental else d, hermi)
+        finally:
+            if announce and incremental:
+                announce(None)
         vhf = as_t(vj) - 0.5 * as_t(vk)
         if incremental:
             vhf = vhf + as_t(vhf_last)
@@ -315,17 +323,27 @@ class _TileTables:
         return self._pair_tab32
 
 
-def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float, want, shard=None):
+def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float, want, shard=None, log_cut64=None, split=None):
     """Task tables of the tiled kernels for one call: {ang: (int32[ntasks, 8], nblocks, nprim patterns, coarse index)}
-    with rows (ij0, nij, kl0, nkl, nchunk, blk0, counter slot, kchunk | nsplit << 16) (include/jqc_hip.h)."""
+    with rows (ij0, nij, kl0, nkl, nchunk, blk0, counter slot, kchunk | nsplit << 16) (include/jqc_hip.h).
+
+    ``log_cut64`` + ``split(ang)`` (mixed precision, single rank): the precision windows applied to whole TILE PAIRS.  A task row
+    (strip of the Schwarz-sorted bra list x leading ket pairs) is cut at the first ket pair whose bound with the strip's STRONGEST
+    bra pair is at or below cutoff_fp64: every quartet behind the cut has an estimate <= cutoff_fp64 whatever its bra pair, i.e.
+    lies in the reference's FP32 window (screen_jk_tasks.cu:241-261), and goes to the FP32 kernel of the class; everything in
+    front of it goes to the FP64 kernel (its FP32-eligible quartets included).  No tile pair is staged by both launches -- the
+    second staging pass is what made the per-quartet split of the reference (jk.py:293-328) a loss on this chip.  Returns
+    (plans of the FP64 parts, plans of the FP32 parts)."""
     from ..constants import tile_width
     gkey = layout.group_key
     ng = layout.ngroups
     pair_cut = math.log(PAIR_CUTOFF) - log_max_dm
     nkeep = {k: int(np.searchsorted(-q, -pair_cut, side="left")) for k, q in tt.q_host.items()}
     per_class: Dict[Tuple[int, int, int, int], list] = {}
+    per_class32: Dict[Tuple[int, int, int, int], list] = {}
     strip_no = 0
     rank, world = shard if shard is not None else (0, 1)
+    two = log_cut64 is not None and world == 1
     for gi in range(ng):
         for gj in range(gi + 1):
             nij_all = nkeep.get((gi, gj), 0)
@@ -342,6 +360,7 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
                         continue
                     qkl = tt.q_host[gk, gl]
                     rows = per_class.setdefault(ang, [])
+                    cut_here = two and (split is None or split(ang))
                     strip = max(1, -(-nij_all // STRIPS_PER_LIST))
                     for s0 in range(0, nij_all, strip):
                         n_ij = min(strip, nij_all - s0)
@@ -349,12 +368,28 @@ def build_tile_plan(layout, tt: "_TileTables", log_cut: float, log_max_dm: float
                         n_kl = min(nkl_all, int(np.searchsorted(-qkl, -thr, side="left")))
                         if n_kl <= 0:
                             break
-                        rows.append((tt.offset[gi, gj] + s0, n_ij, tt.offset[gk, gl], n_kl,
-                                     (int(gkey[gi, 1]), int(gkey[gj, 1]), int(gkey[gk, 1]), int(gkey[gl, 1]))))
+                        npr = (int(gkey[gi, 1]), int(gkey[gj, 1]), int(gkey[gk, 1]), int(gkey[gl, 1]))
+                        n64 = n_kl
+                        if cut_here:       # ket pairs [n64, n_kl): bound <= cutoff_fp64 with the strongest bra pair of the strip
+                            n64 = min(n_kl, int(np.searchsorted(-qkl, -(log_cut64 - log_max_dm - float(qij[s0])), side="left")))
+                            if n_kl > n64:
+                                per_class32.setdefault(ang, []).append((tt.offset[gi, gj] + s0, n_ij, tt.offset[gk, gl] + n64,
+                                                                        n_kl - n64, npr))
+                        if n64 > 0:
+                            rows.append((tt.offset[gi, gj] + s0, n_ij, tt.offset[gk, gl], n64, npr))
     if world > 1:
         owner, load = _shard_assign(per_class, world)          # (one O(rows x world) pass per plan)
         build_tile_plan.last_predicted_load = load             # ns per rank (diagnostics, tests)
         per_class = _shard_rows(per_class, rank, world, owner)
+    plans = _finish_tile_plans(per_class)
+    if log_cut64 is not None:
+        return plans, _finish_tile_plans(per_class32)
+    return plans
+
+
+def _finish_tile_plans(per_class):
+    """Launch geometry (ket chunks, workgroup splits, block offsets, coarse index) of every class's task rows."""
+    from ..constants import tile_width
     plans = {}
     for ang, rows in per_class.items():
         if not rows:
@@ -605,36 +640,51 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
             tt = state["tiles"][om]
             # the plan only depends on the density through log_max_dm: bucket it (upwards = looser, safe)
             bucket = math.ceil(log_max_dm * 2.0) / 2.0
-            pkey = (om, bucket, shard)
+            # mixed precision by TILE PAIRS (build_tile_plan): the classes of the measured table (gfx950_scheme.json
+            # "fp32_tile_split") hand the tile pairs whose bound is at or below cutoff_fp64 to their FP32 kernel
+            tsplit = (lambda a: _router.fp32_tile_split(a)) if (mixed and not fp32_only and shard is None) else None
+            # an INCREMENT of a density matrix (get_veff sets ``increment_of`` = largest element of the full matrix) is cut where a
+            # build of the full matrix would be cut: FP32 rounding relative to the increment's own size would otherwise spread
+            # over ever more tile pairs as the increments shrink (the grid path's lesson)
+            ref = state.get("increment_of")
+            ref_bucket = max(bucket, math.ceil(math.log(ref) * 2.0) / 2.0) if ref else bucket
+            pkey = (om, bucket, shard, tsplit is not None and (os.environ.get("JQC_FP32_TILE_SPLIT"), ref_bucket))
             if pkey not in state["plan_cache"]:
-                tplans = build_tile_plan(layout, tt, log_cutoff_fp32, bucket, is_tile, shard)
+                if tsplit is not None:
+                    tplans, tplans32 = build_tile_plan(layout, tt, log_cutoff_fp32, bucket, is_tile, shard,
+                                                       log_cut64=log_cutoff_fp64 - (ref_bucket - bucket), split=tsplit)
+                else:
+                    tplans, tplans32 = build_tile_plan(layout, tt, log_cutoff_fp32, bucket, is_tile, shard), {}
                 entry = None
-                if tplans:
+                if tplans or tplans32:
                     from ..roofline import quartet_flops
-                    cost = {a: sum(int(r[1]) * int(r[3]) for r in tplans[a][0]) * quartet_flops(a) for a in tplans}
-                    order = sorted(tplans, key=lambda a: -cost[a])              # longest first over the streams
-                    tabs = np.concatenate([tplans[a][0] for a in order])
+                    plan_of = lambda it: (tplans32 if it[1] else tplans)[it[0]]
+                    items = [(a, False) for a in tplans] + [(a, True) for a in tplans32]      # (class, FP32 part?)
+                    cost = {it: sum(int(r[1]) * int(r[3]) for r in plan_of(it)[0]) * quartet_flops(it[0]) for it in items}
+                    order = sorted(items, key=lambda it: -cost[it])              # longest first over the streams
+                    tabs = np.concatenate([plan_of(it)[0] for it in order])
                     tabs[:, 6] = np.arange(tabs.shape[0])                       # counter slot of every task row
-                    index = np.concatenate([tplans[a][3] for a in order])
+                    index = np.concatenate([plan_of(it)[3] for it in order])
                     ioff, pos = {}, 0
-                    for a in order:
-                        ioff[a] = pos
-                        pos += tplans[a][3].size
+                    for it in order:
+                        ioff[it] = pos
+                        pos += plan_of(it)[3].size
                     entry = {"order": order, "tabs_d": torch.from_numpy(tabs).to(dev), "nrows": tabs.shape[0],
                              "index_d": torch.from_numpy(index).to(dev), "index_off": ioff,
-                             "plans": tplans, "row_meta": [(a, npr) for a in order for npr in tplans[a][2]]}
+                             "plans": tplans, "plans32": tplans32,
+                             "row_meta": [(it[0], npr) for it in order for npr in plan_of(it)[2]]}
                 if len(state["plan_cache"]) > 64:
                     state["plan_cache"].clear()
                 state["plan_cache"][pkey] = entry
             entry = state["plan_cache"][pkey]
             if entry is not None:
-                order, tabs_d, tplans = entry["order"], entry["tabs_d"], entry["plans"]
+                order, tabs_d, tplans, tplans32 = entry["order"], entry["tabs_d"], entry["plans"], entry["plans32"]
                 # 32 leading slots: diagnostic cycle stamps of -DSTAMPS=1 kernel builds (tools/stamps_profile.py)
                 counts_buf = torch.zeros(32 + 2 * entry["nrows"], dtype=torch.int64, device=dev)
                 tile_counts = counts_buf[32:].view(2, entry["nrows"])
                 state["stats"]["stamps"] = counts_buf[:32]
                 nst = state["nstreams"]
-                if state["auto_streams"] and sum(int(tplans[a][1]) for a in order) > BIG_CALL_WGS:
+                if state["auto_streams"] and sum(int((tplans32 if f32 else tplans)[a][1]) for a, f32 in order) > BIG_CALL_WGS:
                     nst = min(nst, N_STREAMS_BIG)
                 if state["streams"] is None or len(state["streams"]) != nst:
                     state["streams"] = [torch.cuda.Stream(device=dev) for _ in range(nst)]
@@ -648,14 +698,35 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     st_.wait_event(ev)
                 row = 0
                 only = __import__('os').environ.get("JQC_ONLY_CLASS")
-                for n, ang in enumerate(order):
-                    tab, nblk, _, _ = tplans[ang]
+                for n, (ang, part32) in enumerate(order):
+                    tab, nblk, _, _ = (tplans32 if part32 else tplans)[ang]
                     if (only and "%d%d%d%d" % tuple(ang) not in only.split(",")) or (_classes is not None and not _classes(ang)):
                         row += tab.shape[0]
                         continue
-                    idx_p = entry["index_d"].data_ptr() + entry["index_off"][ang] * 4
+                    idx_p = entry["index_d"].data_ptr() + entry["index_off"][(ang, part32)] * 4
                     sid = side[n % len(side)]
                     sp = sid.cuda_stream
+                    if part32:
+                        # tile pairs whose every quartet lies in the FP32 window: the FP32 kernel of the class, nobody else
+                        algo32 = _router.select_algo(ang, True)
+                        if n_dm > 1 and NDM2 and _router.supports_ndm2(ang, algo32):
+                            algo32 |= _router.VARIANT_NDM2
+                        h32 = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=True, algo=algo32)
+                        first_use_check(ang, algo32, True, h32, bucket)
+                        probing = state["probe"] is not None and (state["probe"] == "all" or tuple(state["probe"]) == tuple(ang))
+                        if probing:
+                            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            ev0.record(sid)
+                        tile_launch(h32, True, vj_p, vk_p, log_cutoff_fp32, INF, tile_counts[1].data_ptr(), sp,
+                                    tabs_d.data_ptr() + row * 32, tab.shape[0], nblk, idx_p)
+                        n_launch += 1
+                        if probing:
+                            ev1.record(sid)
+                            state["stats"].setdefault("probe_events", []).append((ev0, ev1))
+                            state["stats"].setdefault("probe_classes", []).append(tuple(ang))
+                        row += tab.shape[0]
+                        continue
+                    tile_split_class = tsplit is not None and tsplit(ang)
                     algo64 = _router.select_algo(ang, small=nblk < TARGET_WGS)
                     if n_dm > 1 and NDM2 and _router.supports_ndm2(ang, algo64):
                         # every pair of density matrices is contracted against ONE evaluation of the integrals
@@ -672,10 +743,10 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                     # -- where that kernel is measured faster per quartet than the fp64 one (gfx950_scheme.json "fp32_pays");
                     # elsewhere the fp64 kernel takes both windows in ONE launch (more accurate and, on this chip, faster:
                     # two launches stage and screen every tile pair twice)
-                    split = mixed and (fp32_only or _router.fp32_pays(ang))
+                    split = mixed and not tile_split_class and (fp32_only or _router.fp32_pays(ang))
                     # ... or BOTH windows in one launch of the fused build (JQC_VARIANT_MIXED: FP64 phase + packed-FP32 phase, two
                     # quartets per lane, behind one staging / screening / flush of every tile pair)
-                    fused = mixed and not split and n_dm == 1 and _router.mixed_fused(ang, algo64)
+                    fused = mixed and not split and not tile_split_class and n_dm == 1 and _router.mixed_fused(ang, algo64)
                     if fused:
                         amx = _router.mixed_variant(ang, algo64)
                         hmx = _router.gen_jk_kernel(ang, do_j=with_j, do_k=with_k, rys_lr=lr, fp32=False, algo=amx)
@@ -793,6 +864,11 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
         state["nstreams"] = max(1, int(n))
         state["auto_streams"] = False
 
+    def set_increment_of(dmax):
+        """The next calls evaluate increments of a density matrix whose largest element is ``dmax`` (None: full matrices again)."""
+        state["increment_of"] = float(dmax) if dmax else None
+
+    get_jk.set_increment_of = set_increment_of
     get_jk.set_streams = set_streams
     get_jk.set_probe = set_probe
     get_jk.quartet_counts = quartet_counts

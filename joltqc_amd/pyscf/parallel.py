@@ -74,7 +74,7 @@ def drive_jk(get_jk_sharded):
         if isinstance(dm, np.ndarray) and getattr(get_jk, "return_numpy", False):
             out = tuple(x.cpu().numpy() if torch.is_tensor(x) else x for x in out)
         return out
-    for k in ("quartet_counts", "stats", "layout", "set_probe", "set_streams"):
+    for k in ("quartet_counts", "stats", "layout", "set_probe", "set_streams", "set_increment_of"):
         if hasattr(get_jk_sharded, k):
             setattr(get_jk, k, getattr(get_jk_sharded, k))
     get_jk.return_numpy = False

@@ -622,7 +622,14 @@ def generate_get_veff():
         if not is_hybrid:
             vk = None
             if incremental:
-                vj = _t(ks.get_j(mol, ddm, hermi), dev) + _t(vhf_last.vj, dev)
+                announce = getattr(ks.get_jk, "set_increment_of", None)       # (see the hybrid branch)
+                if announce:
+                    announce(float(dm_t.abs().max()))
+                try:
+                    vj = _t(ks.get_j(mol, ddm, hermi), dev) + _t(vhf_last.vj, dev)
+                finally:
+                    if announce:
+                        announce(None)
             else:
                 vj = _t(ks.get_j(mol, dm_t, hermi), dev)
             vxc = vxc + vj
@@ -630,10 +637,18 @@ def generate_get_veff():
             omega, alpha, hyb = ni.rsh_and_hybrid_coeff(ks.xc, spin=getattr(mol, "spin", 0))
             last = incremental
             d = ddm if last else dm_t
-            vj, vk = ks.get_jk(mol, d, hermi)
-            vj, vk = _t(vj, dev), _t(vk, dev) * hyb
-            if abs(omega) > 1e-10:                    # long-range exchange of range-separated hybrids
-                vk = vk + _t(ks.get_k(mol, d, hermi, omega=omega), dev) * (alpha - hyb)
+            # (mixed-precision J/K of an increment is split where a build of the full matrix would be split: pyscf/jk.py)
+            announce = getattr(ks.get_jk, "set_increment_of", None) if last else None
+            if announce:
+                announce(float(dm_t.abs().max()))
+            try:
+                vj, vk = ks.get_jk(mol, d, hermi)
+                vj, vk = _t(vj, dev), _t(vk, dev) * hyb
+                if abs(omega) > 1e-10:                    # long-range exchange of range-separated hybrids
+                    vk = vk + _t(ks.get_k(mol, d, hermi, omega=omega), dev) * (alpha - hyb)
+            finally:
+                if announce:
+                    announce(None)
             if last:
                 vj = vj + _t(vhf_last.vj, dev)
                 vk = vk + _t(vhf_last.vk, dev)

@@ -328,3 +328,32 @@ def test_north_star_112_atoms_rhf_tzvpp_scf_through_apply():
         runs.append((e, mf.cycles, time.time() - t))
     print("112 atoms RHF/def2-TZVPP:", runs)
     assert runs[0][0] < -2600.0 and abs(runs[0][0] - runs[1][0]) < 1e-8, runs
+
+
+def test_mixed_precision_jk_scf_112_atoms_svp(monkeypatch):
+    """Mixed-precision J/K through a whole SCF (BASELINE config 4's precision mode at the config-3 size): RHF / def2-SVP on the 112-atom
+    molecule through ``apply()`` with the J/K windows 1e-13 / 1e-7 and the tile-pair split forced on for EVERY class (the FP32 kernels
+    take the tile pairs whose bound is at or below 1e-7; increments are split where a build of the full density would be split),
+    against the all-FP64 run: both converge on PySCF's criteria and agree to 1e-7 Eh -- FP32 rounding does not pile up over the
+    incremental builds (the reference's own bar between precisions is 1e-5, jqc/pyscf/tests/test_scf.py)."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.pyscf import int1e
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from standin_scf import RHF, atomic_density_guess
+    mol = _mol112("def2-svp")
+    dm0 = atomic_density_guess(mol)
+    S, T, V = (x.cpu().numpy() for x in int1e.int1e(BasisLayout.from_mol(mol, alignment=1), mol))
+    monkeypatch.setenv("JQC_FP32_TILE_SPLIT", "1")
+    out = {}
+    for label, c64 in (("mixed", 1e-7), ("fp64", 1e-13)):
+        cfg = jp.get_default_config()
+        cfg["jk"] = {"cutoff_fp32": 1e-13, "cutoff_fp64": c64, "pair_j": False}
+        mf = RHF(mol, T + V, S)
+        mf.max_cycle = 50
+        mf = jp.apply(mf, cfg)
+        e = mf.kernel(dm0=dm0)
+        assert mf.converged, (label, mf.cycles)
+        n64, n32, _ = mf.get_jk.quartet_counts()          # (of the last J/K call)
+        out[label] = (e, mf.cycles, n64, n32)
+    assert out["mixed"][3] > 0 and out["fp64"][3] == 0, out
+    assert abs(out["mixed"][0] - out["fp64"][0]) < 1e-7, out

@@ -115,6 +115,33 @@ def test_mixed_precision_with_the_fp32_window_split_off(monkeypatch):
     assert np.abs(_np(vj) - rj).max() < 1e-7 and np.abs(_np(vk) - rk).max() < 1e-7
 
 
+def test_mixed_precision_split_by_tile_pairs(monkeypatch):
+    """Mixed precision as this build applies it (pyscf/jk.py build_tile_plan): the tile pairs whose bound is at or below cutoff_fp64
+    go to the FP32 kernel of their class, everything else to the FP64 kernel, no tile pair to both.  Forced on for every class on two
+    benzene rings 14 Bohr apart (many weak shell pairs): both parts get work, every quartet is evaluated exactly once, and the
+    result holds the reference's bar for mixed precision (1e-7, jqc/pyscf/tests/test_jk.py:218-248)."""
+    from oracle import dense
+    from conftest import benzene_atoms
+    ring = benzene_atoms()
+    atoms = ring + [(sym, (x + 7.4, y + 0.5, z + 1.0)) for sym, (x, y, z) in ring]
+    monkeypatch.setenv("JQC_FP32_TILE_SPLIT", "1")
+    mol, lay, jkmix = _setup(atoms, "def2-svp", cut64=1e-7, cut32=1e-13)
+    np.random.seed(4)
+    c = np.random.rand(mol.nao, mol.nelectron // 2) - 0.5
+    dm = 2 * c @ c.T / mol.nao
+    vj, vk = jkmix(mol, dm, hermi=1)
+    n64, n32, _ = jkmix.quartet_counts()
+    monkeypatch.setenv("JQC_FP32_TILE_SPLIT", "0")
+    _, _, jk64 = _setup(atoms, "def2-svp", cut64=1e-7, cut32=1e-13)
+    rj, rk = jk64(mol, dm, hermi=1)                       # the FP64 kernels on both windows (checked against the oracle elsewhere)
+    m64, m32, _ = jk64.quartet_counts()
+    assert n32 > 0 and n64 > 0 and m32 == 0 and n64 + n32 == m64, (n64, n32, m64, m32)
+    assert float((vj - rj).abs().max()) < 1e-7 and float((vk - rk).abs().max()) < 1e-7
+    assert float((vj - rj).abs().max()) > 0.0             # (the FP32 kernels really ran)
+    oj, ok = dense.get_jk(lay, dm, hermi=1, cutoff=1e-15)
+    assert np.abs(_np(vj) - oj).max() < 1e-7 and np.abs(_np(vk) - ok).max() < 1e-7
+
+
 def test_jk_screening_far_apart_atoms():
     # reference test_jk.py:250-276: 100 Bohr apart -> inter-atomic quartets are screened out
     from oracle import dense

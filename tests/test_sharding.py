@@ -176,3 +176,29 @@ def test_predicted_load_is_balanced_for_2_4_8_ranks(name, basis):
         assert router.class_key(a) in cost, a
     for l4 in [(4, 0, 0, 0), (4, 4, 4, 4), (4, 3, 2, 1)]:
         assert router.class_key(l4) in cost, l4
+
+
+def test_precision_split_by_tile_pairs_partitions_the_plan():
+    """Mixed precision by tile pairs (``build_tile_plan(log_cut64=...)``): the FP64 part and the FP32 part together cover exactly the
+    quartets of the unsplit plan, no quartet twice, and every quartet of the FP32 part has an estimate q_ij + q_kl + log max|D| at or
+    below cutoff_fp64 -- the reference's FP32 window (jqc/backend/jk/screen_jk_tasks.cu:241-261), so no quartet the reference would
+    evaluate in FP64 is evaluated in FP32."""
+    from joltqc_amd.pyscf import jk as jkmod
+    mol, lay, q, tt = _layout_and_tables()
+    log_cut, log_dm = float(np.log(1e-13)), 0.0
+    full = jkmod.build_tile_plan(lay, tt, log_cut, log_dm, lambda a: True)
+    both = 0
+    for cut64 in (3.0, 0.3, 1e-2, 1e-7):
+        log_cut64 = float(np.log(cut64))
+        p64, p32 = jkmod.build_tile_plan(lay, tt, log_cut, log_dm, lambda a: True, log_cut64=log_cut64, split=lambda a: True)
+        q64 = _plan_quartets(lay, tt, p64, q, log_cut, log_dm)
+        q32 = _plan_quartets(lay, tt, p32, q, log_cut, log_dm)
+        assert not (q64 & q32)
+        assert (q64 | q32) == _plan_quartets(lay, tt, full, q, log_cut, log_dm)
+        assert all(q[i, j] + q[k, l] + log_dm <= log_cut64 + 1e-5 for i, j, k, l in q32)
+        both += bool(q32) and bool(q64)
+    assert both >= 1                                # (H2O / def2-SVP: the bounds lie around 1e-1 .. 1e1)
+    # classes the predicate leaves out stay whole
+    p64, p32 = jkmod.build_tile_plan(lay, tt, log_cut, log_dm, lambda a: True, log_cut64=float(np.log(3.0)), split=lambda a: a[0] < 2)
+    assert all(a[0] < 2 for a in p32)
+    assert sum(pl[0].shape[0] for a, pl in p64.items() if a[0] >= 2) == sum(pl[0].shape[0] for a, pl in full.items() if a[0] >= 2)
