@@ -642,13 +642,15 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
             bucket = math.ceil(log_max_dm * 2.0) / 2.0
             # mixed precision by TILE PAIRS (build_tile_plan): the classes of the measured table (gfx950_scheme.json
             # "fp32_tile_split") hand the tile pairs whose bound is at or below cutoff_fp64 to their FP32 kernel
-            tsplit = (lambda a: _router.fp32_tile_split(a)) if (mixed and not fp32_only and shard is None) else None
+            # (J+K calls only: the mode the table was measured in and whose FP32 builds are compiled ahead of time and gated)
+            tsplit = (lambda a: _router.fp32_tile_split(a)) if (mixed and not fp32_only and shard is None and with_j and with_k) else None
             # an INCREMENT of a density matrix (get_veff sets ``increment_of`` = largest element of the full matrix) is cut where a
             # build of the full matrix would be cut: FP32 rounding relative to the increment's own size would otherwise spread
             # over ever more tile pairs as the increments shrink (the grid path's lesson)
             ref = state.get("increment_of")
             ref_bucket = max(bucket, math.ceil(math.log(ref) * 2.0) / 2.0) if ref else bucket
-            pkey = (om, bucket, shard, tsplit is not None and (os.environ.get("JQC_FP32_TILE_SPLIT"), ref_bucket))
+            pkey = (om, bucket, shard, tsplit is not None and (os.environ.get("JQC_FP32_TILE_SPLIT"), ref_bucket))        # (with_j / with_k do not
+                                                                                                                          #  enter the plan otherwise)
             if pkey not in state["plan_cache"]:
                 if tsplit is not None:
                     tplans, tplans32 = build_tile_plan(layout, tt, log_cutoff_fp32, bucket, is_tile, shard,
