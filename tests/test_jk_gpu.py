@@ -74,6 +74,13 @@ def test_jk_hermi0_and_long_range():
     rj, rk = dense.get_jk(lay, dm, hermi=0)
     assert np.abs(_np(vj) - rj).max() < 1e-9 and np.abs(_np(vk) - rk).max() < 1e-9
     dms = _dm(mol.nao)
+    # a SYMMETRIC matrix passed with the signature's default hermi = 0 takes the one-matrix path (same result; the stacked
+    # [D, D^T] call of a non-symmetric matrix costs 1.49x a hermi = 1 call)
+    vj0, vk0 = get_jk(mol, dms)                     # (hermi defaults to 0)
+    rj, rk = dense.get_jk(lay, dms, hermi=0)
+    assert np.abs(_np(vj0) - rj).max() < 1e-9 and np.abs(_np(vk0) - rk).max() < 1e-9
+    vj1, vk1 = get_jk(mol, dms, hermi=1)
+    assert float((vj0 - vj1).abs().max()) < 1e-12 and float((vk0 - vk1).abs().max()) < 1e-12
     for omega in (0.3, 0.5):                        # reference test_jk.py:171-216
         vj, vk = get_jk(mol, dms, hermi=1, omega=omega)
         rj, rk = dense.get_jk(lay, dms, hermi=1, omega=omega)
