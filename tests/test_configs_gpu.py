@@ -64,15 +64,20 @@ def test_config4_166_atoms_tzvpp_jk_mixed_precision_and_long_range(monkeypatch):
     # mixed precision: the reference's windows (estimate in (1e-13, 1e-7] -> FP32 kernel); bar of its own test: 1e-7
     gm = jkmod.generate_jk_kernel(lay, cutoff_fp64=1e-7, cutoff_fp32=1e-13)
     mj, mk = gm(mol, dm, hermi=1)
+    m64, m32, _ = gm.quartet_counts()
+    # (the default mixed mode: the FP32 kernels of 24 classes take their low-bound tile pairs -- it must really use them)
+    assert m32 > 0 and abs(m64 + m32 - n64) < 1e-4 * n64, (m64, m32, n64)
     assert float((mj - vj).abs().max()) < 1e-7 and float((mk - vk).abs().max()) < 1e-7
-    # ... and with the FP32 window really evaluated in FP32: the fused builds of the lane-per-quartet classes (FP64 phase + packed
+    # ... and with the FP32 window evaluated in FP32 per QUARTET: the fused builds of the lane-per-quartet classes (FP64 phase + packed
     # FP32 phase in one launch) forced on -- measured slower than the fp64 kernels on this chip, hence not the default
     # (profiles/r04_mixed_fused_packed_fp32.txt), but the precision split itself must hold the reference's bar
     monkeypatch.setenv("JQC_MIXED_FUSED", "1")
+    monkeypatch.setenv("JQC_FP32_TILE_SPLIT", "0")
     gf = jkmod.generate_jk_kernel(lay, cutoff_fp64=1e-7, cutoff_fp32=1e-13)
     fj, fk = gf(mol, dm, hermi=1)
     f64, f32, _ = gf.quartet_counts()
     monkeypatch.delenv("JQC_MIXED_FUSED")
+    monkeypatch.delenv("JQC_FP32_TILE_SPLIT")
     assert f32 > 0.2 * n64 and abs(f64 + f32 - n64) < 1e-4 * n64, (f64, f32, n64)
     assert float((fj - vj).abs().max()) < 1e-7 and float((fk - vk).abs().max()) < 1e-7
     # what an RSH functional asks of get_jk: long-range K only -- tiled kernels vs the independent queue kernels

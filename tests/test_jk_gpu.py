@@ -361,6 +361,8 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     fused = mode.startswith("fused")
     if fused:
         monkeypatch.setenv("JQC_MIXED_FUSED", "1")
+        monkeypatch.setenv("JQC_FP32_TILE_SPLIT", "0")        # (the default mixed mode of 24 classes -- FP32 kernels on the low-bound
+                                                             #  tile pairs -- would take these classes away from the fused builds)
         # (three atoms 2-3 Bohr apart and a density of O(10) elements: the estimates Q_ij Q_kl |D| of this system lie around 1e0 - 1e2)
         cut64, tol = (1e20, 2e-5) if mode == "fused32" else (30.0, 2e-5)
     bad, nclass, nfused, nboth = [], 0, 0, 0
