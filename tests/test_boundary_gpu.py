@@ -3,6 +3,8 @@ NumPy in / NumPy out, ``reset`` / ``as_scanner`` after a geometry change (refere
 range-separated-hybrid and VV10 branches of the RKS ``get_veff`` (reference jqc/pyscf/rks.py:184-260, :661-714).
 When PySCF itself is importable (not in this image) the same is repeated on real ``scf.RHF`` / ``dft.RKS`` objects against
 the reference's hard-coded energies (jqc/pyscf/tests/test_scf.py:70,77)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -310,3 +312,42 @@ def test_two_ranks_through_apply_rank0_owns_the_object():
     assert res[0]["n_grad"] + res[1]["n_grad"] == mf._jqc_jk_energy_per_atom.quartet_count() and min(res[0]["n_grad"], res[1]["n_grad"]) > 0
     b0, b1 = res[1]["range"]
     assert 0 < b0 < b1 == res[0]["blocks"]                                  # rank 1 took the upper range of the grid blocks
+
+
+def _rccl_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))       # backend "nccl" IS RCCL on ROCm
+    from joltqc_amd.pyscf import parallel as par
+    assert par.world() == (0, 1) and par._device().type == "cuda"
+    # the collectives of the multi-GPU path on device buffers of its own sizes: header + density broadcast (parallel.py), the ONE
+    # all-reduce of the raw [vj; vk] of config 5 (2 x 4 400^2 doubles = 310 MB, pyscf/jk.py)
+    h = par._bcast_header([par.OP_JK, 2, 1, 4400, 1, 1, 1, 0.0])
+    d = par._bcast_matrix(torch.ones((64, 64), dtype=torch.float64), (64, 64))
+    fock = torch.full((2, 4400, 4400), 0.5, dtype=torch.float64, device="cuda")
+    dist.all_reduce(fock)
+    torch.cuda.synchronize()
+    q.put((h[:4], float(d.sum()), float(fock.sum()), d.is_cuda))
+    dist.destroy_process_group()
+
+
+def test_rccl_initialises_and_runs_the_collectives_of_the_multi_gpu_path():
+    """One GPU per box here, so the N > 1 path runs on gloo in this suite; what CAN be exercised on hardware is RCCL itself:
+    ``init_process_group("nccl")`` (world size 1), the header / matrix broadcasts of pyscf/parallel.py on device tensors and the
+    all-reduce of a Fock-sized buffer -- the calls ``bench.py --gpus N`` and ``apply(mf, {"parallel": True})`` make."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    head, dsum, fsum, on_dev = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert head == [1.0, 2.0, 1.0, 4400.0] and dsum == 64.0 * 64.0 and on_dev
+    assert abs(fsum - 0.5 * 2 * 4400 * 4400) < 1e-3
