@@ -22,11 +22,15 @@ nocc = mol.nelectron // 2
 c = np.random.rand(mol.nao, nocc) - 0.5
 dm = torch.from_numpy(c @ c.T / nocc).cuda()
 res, ref, out = {}, None, {}
-for label, c64, env in (("fp64", 1e-13, None), ("split", 1e-7, None if use_table else "1")):
-    if env is None:
-        os.environ.pop("JQC_FP32_TILE_SPLIT", None)
-    else:
-        os.environ["JQC_FP32_TILE_SPLIT"] = env
+# third leg: the reference's per-QUARTET split (fp64 launch on (cutoff_fp64, inf), fp32 launch on (cutoff_fp32, cutoff_fp64]: every tile
+# pair staged twice), forced on for every class
+for label, c64, env, win in (("fp64", 1e-13, None, None), ("split", 1e-7, None if use_table else "1", None if use_table else "0"),
+                            ("window", 1e-7, "0", "1")):
+    for k, v in (("JQC_FP32_TILE_SPLIT", env), ("JQC_FP32_WINDOW", win)):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     g = jkmod.generate_jk_kernel(lay, cutoff_fp64=c64, cutoff_fp32=1e-13)
     for _ in range(2):
         vj, vk = g(mol, dm, hermi=1)
@@ -57,16 +61,18 @@ for label, c64, env in (("fp64", 1e-13, None), ("split", 1e-7, None if use_table
     res[label] = {"ms": tm, "counts": cnt}
     if label == "fp64":
         ref = (vj.clone(), vk.clone())
-    else:
+    if label != "fp64":
         out[label]["max_abs_dev_j"] = float((vj - ref[0]).abs().max()); out[label]["max_abs_dev_k"] = float((vk - ref[1]).abs().max())
         out[label]["max_j"], out[label]["max_k"] = float(ref[0].abs().max()), float(ref[1].abs().max())
 print(json.dumps(out))
 tot64 = tots = 0.0
+totw = 0.0
 for k in sorted(res["fp64"]["ms"], key=lambda k: -res["fp64"]["ms"][k]):
-    a, b = res["fp64"]["ms"][k], res["split"]["ms"].get(k, float("nan"))
-    n = res["split"]["counts"].get(k, [0, 0])
-    tot64 += a; tots += b
-    print(f"{k}: fp64 {a:8.2f} ms  split {b:8.2f} ms  ratio {b / a:.3f}  fp32 share {n[1] / max(n[0] + n[1], 1):.2f}")
-print(f"serial sums: fp64 {tot64:.1f} ms  split {tots:.1f} ms  ratio {tots / tot64:.3f}")
+    a, b, w = res["fp64"]["ms"][k], res["split"]["ms"].get(k, float("nan")), res["window"]["ms"].get(k, float("nan"))
+    n, nw = res["split"]["counts"].get(k, [0, 0]), res["window"]["counts"].get(k, [0, 0])
+    tot64 += a; tots += b; totw += w
+    print(f"{k}: fp64 {a:8.2f} ms  tile split {b:8.2f} ms ({b / a:.3f}, fp32 share {n[1] / max(n[0] + n[1], 1):.2f})  "
+          f"quartet window {w:8.2f} ms ({w / a:.3f}, fp32 share {nw[1] / max(nw[0] + nw[1], 1):.2f})")
+print(f"serial sums: fp64 {tot64:.1f} ms  tile split {tots:.1f} ms ({tots / tot64:.3f})  quartet window {totw:.1f} ms ({totw / tot64:.3f})")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"molecule": name, "basis": basis, "whole": out, "per_class": res}, open(os.path.join(ROOT, "gpurun_out", "tile_split_bench.json"), "w"), indent=1)
