@@ -73,11 +73,13 @@ def test_config4_166_atoms_tzvpp_jk_mixed_precision_and_long_range(monkeypatch):
     # (profiles/r04_mixed_fused_packed_fp32.txt), but the precision split itself must hold the reference's bar
     monkeypatch.setenv("JQC_MIXED_FUSED", "1")
     monkeypatch.setenv("JQC_FP32_TILE_SPLIT", "0")
+    monkeypatch.setenv("JQC_FP32_WINDOW", "0")
     gf = jkmod.generate_jk_kernel(lay, cutoff_fp64=1e-7, cutoff_fp32=1e-13)
     fj, fk = gf(mol, dm, hermi=1)
     f64, f32, _ = gf.quartet_counts()
     monkeypatch.delenv("JQC_MIXED_FUSED")
     monkeypatch.delenv("JQC_FP32_TILE_SPLIT")
+    monkeypatch.delenv("JQC_FP32_WINDOW")
     assert f32 > 0.2 * n64 and abs(f64 + f32 - n64) < 1e-4 * n64, (f64, f32, n64)
     assert float((fj - vj).abs().max()) < 1e-7 and float((fk - vk).abs().max()) < 1e-7
     # what an RSH functional asks of get_jk: long-range K only -- tiled kernels vs the independent queue kernels

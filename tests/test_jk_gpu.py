@@ -139,6 +139,7 @@ def test_mixed_precision_split_by_tile_pairs(monkeypatch):
     vj, vk = jkmix(mol, dm, hermi=1)
     n64, n32, _ = jkmix.quartet_counts()
     monkeypatch.setenv("JQC_FP32_TILE_SPLIT", "0")
+    monkeypatch.setenv("JQC_FP32_WINDOW", "0")            # (nor the per-quartet split a few classes use by default)
     _, _, jk64 = _setup(atoms, "def2-svp", cut64=1e-7, cut32=1e-13)
     rj, rk = jk64(mol, dm, hermi=1)                       # the FP64 kernels on both windows (checked against the oracle elsewhere)
     m64, m32, _ = jk64.quartet_counts()
@@ -361,8 +362,8 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
     fused = mode.startswith("fused")
     if fused:
         monkeypatch.setenv("JQC_MIXED_FUSED", "1")
-        monkeypatch.setenv("JQC_FP32_TILE_SPLIT", "0")        # (the default mixed mode of 24 classes -- FP32 kernels on the low-bound
-                                                             #  tile pairs -- would take these classes away from the fused builds)
+        monkeypatch.setenv("JQC_FP32_TILE_SPLIT", "0")        # (the default mixed modes -- FP32 kernels on the low-bound tile pairs
+        monkeypatch.setenv("JQC_FP32_WINDOW", "0")            #  or on the per-quartet window -- would take classes away from the fused builds)
         # (three atoms 2-3 Bohr apart and a density of O(10) elements: the estimates Q_ij Q_kl |D| of this system lie around 1e0 - 1e2)
         cut64, tol = (1e20, 2e-5) if mode == "fused32" else (30.0, 2e-5)
     bad, nclass, nfused, nboth = [], 0, 0, 0
