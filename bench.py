@@ -246,6 +246,9 @@ def grid_leg(mol, nsteps=5):
         m = rho_k.stats["nrow_h"].astype(float)
         flm = 4.0 * 2.0 * float((m * m).sum()) * 256 + 10.0 * 256 * float(m.sum())       # four GEMMs (phi, d_x, d_y, d_z) + dots
         mg[label] = {"ms": dtm * 1e3, "tflops": flm / dtm / 1e12, "frac_fp64_mfma_peak": flm / dtm / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+    # (the model counts the four GEMMs of the reference's formulation; since round 4 the vxc kernel computes its three symmetric tau
+    #  passes on and below the diagonal only, i.e. executes ~2.5 of them: the vxc fraction is algorithmic work / time, not MFMA busy)
+    mg["note"] = "vxc: tau passes computed on and below the diagonal (about 2.5 of the 4 model GEMMs are executed)"
     out["meta_gga"] = mg
     # VV10 pair sums (reference dft/vv10.cu): 262 144 points of this grid against themselves, FP32 inner loop / FP64 accumulation,
     # 30 flop per pair against the FP32 vector peak

@@ -1106,8 +1106,13 @@ int jqc_dft_vxc(int blk0, int nblk, int ngrids, const int32_t* nrow_d, const int
 {
     if (nblk <= 0) return 0;
     if (ndim != 1 && ndim != 4 && ndim != 5) return fail(-1, "ndim must be 1 (LDA), 4 (GGA) or 5 (meta-GGA)");
-    hipLaunchKernelGGL(vxc_mfma_kernel, dim3(nblk), dim3(VXC_THREADS), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
-                       (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, wv_d, ndim, nao, vmat_d, row_la_d, thr64, thr32, order_d);
+    // (GGA: T = phi X^T has no symmetric pass; LDA and meta-GGA use the instantiation that computes theirs on and below the diagonal)
+    if (ndim == 4)
+        hipLaunchKernelGGL((vxc_mfma_kernel<false>), dim3(nblk), dim3(VXC_THREADS), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, wv_d, ndim, nao, vmat_d, row_la_d, thr64, thr32, order_d);
+    else
+        hipLaunchKernelGGL((vxc_mfma_kernel<true>), dim3(nblk), dim3(VXC_THREADS), 0, (hipStream_t)stream, blk0, ngrids, nrow_d,
+                           (const long long*)row_base_d, (long long)comp_stride, ws_d, ao_idx_d, wv_d, ndim, nao, vmat_d, row_la_d, thr64, thr32, order_d);
     HIP_OK(hipGetLastError());
     return 0;
 }
