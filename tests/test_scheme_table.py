@@ -146,3 +146,24 @@ def test_risky_builds_are_gated_twice_or_quarantined():
             assert r["ok"] and r["run_to_run"] <= 1e-12 and r["vs_ref"] <= (2e-4 if loose else 1e-10), (key, r)
         else:
             assert key in man["quarantined"], key
+
+
+def test_increment_policy_schedules_full_rebuilds():
+    """rks.IncrementPolicy: a full build on the first call, whenever the increment has shrunk by 1e3 since the last full
+    build, and after 12 increments in a row -- the schedule that keeps dropped sub-cutoff terms and FP32 rounding from piling up over
+    an SCF run (3-4 full builds per run instead of one)."""
+    from joltqc_amd.pyscf.rks import IncrementPolicy
+    p = IncrementPolicy()
+    # |dD|max of the 112-atom B3LYP run (profiles/r04_config3_scf_noise.txt)
+    seq = [2.2, 7.1e-1, 6.0e-1, 4.9e-1, 1.2e-1, 3.6e-2, 1.5e-2, 5.4e-3, 1.6e-3, 4.7e-4, 1.2e-4, 6.3e-5, 2.4e-5, 6.4e-6, 3.3e-6, 9.4e-7,
+           5.9e-7, 3.1e-7, 2.3e-7, 4.3e-8, 1.8e-8]
+    full = [i for i, d in enumerate(seq) if p.full_build(d)]
+    assert full == [0, 8, 15]
+    # a stagnating run is rebuilt every 12 increments
+    p.reset()
+    full = [i for i in range(30) if p.full_build(1e-3)]
+    assert full == [0, 13, 26]
+    # a converged density evaluated again (increment exactly zero) is a full build
+    assert p.full_build(0.0)
+    p.reset()
+    assert p.full_build(5.0) and not p.full_build(4.0)
