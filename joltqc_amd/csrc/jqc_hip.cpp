@@ -877,10 +877,14 @@ int jqc_gen_jk_grad_kernel(int li, int lj, int lk, int ll, int rys_lr, int compi
     snprintf(entry, sizeof entry, "jk_grad_%d%d%d%d", li, lj, lk, ll);
     const std::string out = g_cache_dir + "/" + key + "_" + g_grad_tag + ".hsaco";
     if (!file_exists(out)) {
-        int rc = compile_to("jk_grad.hip", {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
-                                            "-DLK=" + std::to_string(lk), "-DLL=" + std::to_string(ll),
-                                            "-DRYS_LR=" + std::to_string(rys_lr), "-DFP32=0", "-DDO_J=1", "-DDO_K=1",
-                                            "-DGRAD_COOP=" + std::to_string(coop), std::string("-DKNAME=") + entry}, out);
+        std::vector<std::string> gd = {"-DLI=" + std::to_string(li), "-DLJ=" + std::to_string(lj),
+                                       "-DLK=" + std::to_string(lk), "-DLL=" + std::to_string(ll),
+                                       "-DRYS_LR=" + std::to_string(rys_lr), "-DFP32=0", "-DDO_J=1", "-DDO_K=1",
+                                       "-DGRAD_COOP=" + std::to_string(coop), std::string("-DKNAME=") + entry};
+        // the host's copy of the kernel's quartets-per-pass arithmetic (grad_quartets_per_pass) is pinned at compile time: the
+        // cooperative build static_asserts EXPECT_G == G, so a drift between the two stops the build instead of mis-sizing a grid
+        if (coop) gd.push_back("-DEXPECT_G=" + std::to_string(grad_quartets_per_pass(li, lj, lk, ll)));
+        int rc = compile_to("jk_grad.hip", gd, out);
         if (rc) return rc;
     }
     Kernel k;

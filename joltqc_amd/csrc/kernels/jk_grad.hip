@@ -330,6 +330,9 @@ constexpr bool TWO_WG = GRAD_TWO_WG && NFK * NFL <= 18 && 4 * gcap(78 * 1024) >=
 // of two workgroups per CU, up to 60 with one workgroup (512 registers)
 constexpr bool P_REGS = NFK * NFL <= (TWO_WG ? 18 : 60);
 constexpr int G = TWO_WG ? gcap(78 * 1024) : gcap(150 * 1024);
+#ifdef EXPECT_G     // (the generator passes its own evaluation of this arithmetic, jqc_hip.cpp:grad_quartets_per_pass)
+static_assert(EXPECT_G == G, "jqc_hip.cpp:grad_quartets_per_pass is out of sync with the constants of jk_grad.hip");
+#endif
 #if ((LK + 1) * (LK + 2) / 2) * ((LL + 1) * (LL + 2) / 2) <= 100
 #define BUNROLL _Pragma("unroll")          // ket loop of phase B with compile-time record offsets
 #else
