@@ -54,6 +54,10 @@ extern "C" {
                                       kernel walks n_dm in pairs.  Lane-per-quartet builds and owner-reduction builds only */
 #define JQC_VARIANT_RSPLIT(code) ((code) << 22) /* row-lane mode: the Rys roots go through phase A / phase B in code + 1 groups, so the
                                       TRR array in LDS holds nroots / (code + 1) roots per quartet (room for a second workgroup per CU) */
+#define JQC_VARIANT_QUAD (1 << 24)  /* lane-per-quartet mode, classes with a p shell and <= 4 Rys roots: one quartet per QUAD of lanes --
+                                     * lane c of the quad owns Cartesian axis c (its recurrences, a third of the integral block), the
+                                     * 1-D arrays of the neighbouring axes arrive by quad-permute DPP moves, each lane evaluates one Rys
+                                     * root; 64 quartets per pass, <= 256 registers (no AGPR copies) for the 100-180-integral classes */
 #define JQC_VARIANT_MIXED (1 << 21) /* FP64 lane-per-quartet build with BOTH precision windows in one launch: quartets with an
                                       estimate above cut_hi in FP64, those in (cut_lo, cut_hi] in FP32, two per lane as packed
                                       2-vectors (v_pk_fma_f32); one staging / screening / flush per tile pair (replaces the reference's

@@ -64,12 +64,13 @@ def class_key(ang):
 
 VARIANT_ORED, VARIANT_PAROOT, VARIANT_NDM2 = 1 << 18, 1 << 19, 1 << 20     # include/jqc_hip.h
 VARIANT_RSPLIT = lambda code: code << 22      # row-lane mode: Rys roots in code + 1 groups through phase A / B (half the TRR array)
+VARIANT_QUAD = 1 << 24         # lane-per-quartet mode with one quartet per DPP quad of lanes (classes with a p shell, <= 4 Rys roots)
 VARIANT_MIXED = 1 << 21        # both precision windows in one launch of an FP64 lane-per-quartet build (FP32 phase packed)
 
 
 def supports_mixed(ang, v):
     """May variant ``v`` of class ``ang`` be built with the fused FP64 + packed-FP32 compute phases (JQC_VARIANT_MIXED)?"""
-    return (v & 0xf) == _lib.ALGO_TILE1Q and not (v & VARIANT_NDM2)
+    return (v & 0xf) == _lib.ALGO_TILE1Q and not (v & VARIANT_NDM2) and not (v & VARIANT_QUAD)
 
 
 def mixed_variant(ang, v):
@@ -120,6 +121,10 @@ def forced_variant(ang, v):
     if (v & 0xf) == _lib.ALGO_TILE1Q:
         v &= ~(0x30000 | VARIANT_ORED | VARIANT_PAROOT | VARIANT_RSPLIT(3))   # integral chunks, owner reduction, per-root phase A,
                                                                               # root groups: row-lane mode only
+    if (v & VARIANT_QUAD) and ((v & 0xf) != _lib.ALGO_TILE1Q or 1 not in ang or sum(ang) // 2 + 1 > 4):
+        v &= ~VARIANT_QUAD                            # quad form: lane-per-quartet builds of classes with a p shell, <= 4 roots
+    if v & VARIANT_QUAD:
+        v &= ~0xc000                                  # (strided queue / row-ordered contraction belong to the one-lane form)
     if (v & 0xf) != _lib.ALGO_TILE1Q:
         v &= ~(0xf000 | VARIANT_MIXED)                # several ket pairs per iteration, strided queue, row-ordered contraction,
                                                       # fused precision phases: lane-per-quartet mode only

@@ -606,6 +606,9 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     const int v_ecap = (algo_variant >> 16) & 3;
     const int v_ored = (algo_variant >> 18) & 1, v_paroot = (algo_variant >> 19) & 1, v_ndm2 = (algo_variant >> 20) & 1;
     const int v_mixed = (algo_variant >> 21) & 1, v_rsplit = (algo_variant >> 22) & 3;
+    const int v_quad = (algo_variant >> 24) & 1;
+    if (v_quad && (algo != JQC_ALGO_TILE1Q || v_mixed || (li + lj + lk + ll) / 2 + 1 > 4 || (li != 1 && lj != 1 && lk != 1 && ll != 1)))
+        return fail(-1, "JQC_VARIANT_QUAD: lane-per-quartet builds of classes with a p shell and at most four Rys roots");
     if (v_mixed && (algo != JQC_ALGO_TILE1Q || fp32 || v_ndm2))
         return fail(-1, "JQC_VARIANT_MIXED: FP64 lane-per-quartet builds with one density matrix per evaluation only");
     if (v_rsplit && algo != JQC_ALGO_TILE && algo != JQC_ALGO_TILE512)
@@ -622,7 +625,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     const char* src = tiled ? "jk_tile.hip" : "jk_1q1t.hip";
     // per-class entry-point name so that rocprofv3 --stats lists every class separately
     char entry[64];
-    snprintf(entry, sizeof entry, "%s_%d%d%d%d%s", tiled ? (algo == JQC_ALGO_TILE1Q ? "jk_tile1q" : algo == JQC_ALGO_TILE512 ? "jk_tile512" : "jk_tile") : "jk_1q1t",
+    snprintf(entry, sizeof entry, "%s_%d%d%d%d%s", tiled ? (algo == JQC_ALGO_TILE1Q ? (v_quad ? "jk_quad" : "jk_tile1q") : algo == JQC_ALGO_TILE512 ? "jk_tile512" : "jk_tile") : "jk_1q1t",
              li, lj, lk, ll, fp32 ? "_f32" : (v_mixed ? "_mx" : ""));
     const std::string out = g_cache_dir + "/" + key + "_" + g_src_tag + ".hsaco";
     if (!file_exists(out)) {
@@ -648,6 +651,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
         if (v_ndm2) d.push_back("-DNDM=2");
         if (v_mixed) d.push_back("-DMIXED=1");
         if (v_rsplit) d.push_back("-DRSPLIT=" + std::to_string(v_rsplit + 1));
+        if (v_quad) d.push_back("-DQUAD=1");
         if (tiled) {
             // Builds that spill vector registers to scratch also re-read the staging pointers from the kernarg segment
             // (KARG_RELOAD in jk_tile.hip: ~45 fewer SGPRs spilled to VGPR lanes); builds without scratch keep the

@@ -122,8 +122,9 @@ def vv10_kernel(coords, vvcoords, W0, K, W0p, Kp, RpW, chunk=2048):
     return -1.5 * F, U, W
 
 
-def vv10nlc(rho, coords, vvrho, vvweight, vvcoords, nlc_pars):
-    """exc[ngrids], vxc[2, ngrids] of jqc/backend/rks.py:542-715 (thresholding, pre/post algebra)."""
+def vv10nlc(rho, coords, vvrho, vvweight, vvcoords, nlc_pars, sums=vv10_kernel):
+    """exc[ngrids], vxc[2, ngrids] of jqc/backend/rks.py:542-715 (thresholding, pre/post algebra); ``sums`` = the pair-sum
+    routine (NumPy above, or the C statement of the same loop, oracle/jk.py:vv10_sums)."""
     thresh = 1e-10
     rho = np.asarray(rho); vvrho = np.asarray(vvrho)
     m = rho[0] >= thresh
@@ -140,7 +141,7 @@ def vv10nlc(rho, coords, vvrho, vvweight, vvcoords, nlc_pars):
     W0 = np.sqrt(W0tmp + Pi43 * dens)
     K = Kvv * dens ** (1.0 / 6.0)
     dKdR = K / 6.0
-    F, U, W = vv10_kernel(np.asarray(coords)[m], np.asarray(vvcoords)[mi], W0, K, W0p, Kp, idens * np.asarray(vvweight)[mi])
+    F, U, W = sums(np.asarray(coords)[m], np.asarray(vvcoords)[mi], W0, K, W0p, Kp, idens * np.asarray(vvweight)[mi])
     dW0dR = (0.5 * Pi43 * dens - 2.0 * W0tmp) / W0
     dW0dG = W0tmp * dens / (g2 * W0)
     exc = np.zeros(rho.shape[1]); vxc = np.zeros((2, rho.shape[1]))

@@ -40,6 +40,7 @@ def lib():
         L.jqc_oracle_jk_bench.argtypes = [ctypes.c_int, dp, dp, ctypes.c_double, ctypes.POINTER(ctypes.c_uint16), ctypes.c_long,
                                           ctypes.c_int, ctypes.c_int]
         L.jqc_oracle_jk_bench.restype = ctypes.c_double
+        L.jqc_oracle_vv10.argtypes = [ctypes.c_int, dp, dp, dp, ctypes.c_int, dp, dp, dp, dp, dp, dp, dp]
         from joltqc_amd.backend.rys import pack_tables  # data file only (numbers), no product code path
         _BLOB = np.array(pack_tables())
         L.jqc_oracle_set_rys(_BLOB.ctypes.data_as(dp))
@@ -138,3 +139,14 @@ def all_quartets(nbas):
                     if i * nbas + j >= k * nbas + l:
                         out.append((i, j, k, l))
     return np.array(out, dtype=np.uint16).reshape(-1, 4)
+
+
+def vv10_sums(coords, vvcoords, W0, K, W0p, Kp, RpW):
+    """F, U, W of the VV10 double sum, signature of oracle/dft.py:vv10_kernel (jqc_oracle_vv10: reference vv10.cu:86-117 in FP64, OpenMP over the outer points)."""
+    c = np.ascontiguousarray(coords, dtype=np.float64)
+    v = np.ascontiguousarray(vvcoords, dtype=np.float64)
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (W0, K, W0p, Kp, RpW)]
+    n, m = c.shape[0], v.shape[0]
+    F, U, W = np.empty(n), np.empty(n), np.empty(n)
+    lib().jqc_oracle_vv10(n, _dp(c), _dp(a[0]), _dp(a[1]), m, _dp(v), _dp(a[2]), _dp(a[3]), _dp(a[4]), _dp(F), _dp(U), _dp(W))
+    return F, U, W

@@ -455,3 +455,30 @@ void jqc_oracle_schwarz(const double *basis, int nbas, double omega, double *out
     free(blk);
     }
 }
+
+/*
+ * VV10 pair sums in double precision, restating /root/reference/jqc/backend/dft/vv10.cu:86-117:
+ *     g = W0_i R^2 + K_i,  g' = W0p_j R^2 + Kp_j,  gt = g + g',  T = RpW_j / (g' (g gt)^2)
+ *     F_i = -1.5 sum_j T g gt,   U_i = sum_j T (g + gt),   W_i = sum_j T R^2 (g + gt)
+ * (same arithmetic as oracle/dft.py:vv10_kernel, which stays the NumPy statement of it; this one lets the known-answer SCF of
+ * tests/test_dft_known_answers.py finish in seconds).  coords [n][3], vvcoords [m][3].
+ */
+void jqc_oracle_vv10(int n, const double *coords, const double *W0, const double *K, int m, const double *vvcoords,
+                     const double *W0p, const double *Kp, const double *RpW, double *F, double *U, double *W)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        const double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2], w0 = W0[i], k = K[i];
+        double f = 0, u = 0, w = 0;
+        for (int j = 0; j < m; j++) {
+            const double dx = x - vvcoords[3 * j], dy = y - vvcoords[3 * j + 1], dz = z - vvcoords[3 * j + 2];
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            const double gp = r2 * W0p[j] + Kp[j], g = r2 * w0 + k, gt = g + gp;
+            const double t = RpW[j] / (gp * (g * gt) * (g * gt));
+            f += t * g * gt;
+            u += t * (g + gt);
+            w += t * r2 * (g + gt);
+        }
+        F[i] = -1.5 * f; U[i] = u; W[i] = w;
+    }
+}

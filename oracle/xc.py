@@ -27,11 +27,19 @@ def2-TZVPP) are restated here from their published closed forms, with libxc's co
                                                 series in u = gamma s^2 / (1 + gamma s^2)] + B97 correlation (Stoll-partitioned
                                                 PW92, same-spin and opposite-spin series); libxc HYB_GGA_XC_WB97, reference energy
                                                 -76.4486274326 (tests/test_dft.py:99-103)
+  * omega-B97M-V                                Mardirossian, Head-Gordon, JCP 144, 214110 (2016), Table III: range-separated
+                                                hybrid meta-GGA (15 % short-range, 100 % long-range exact exchange, omega = 0.3)
+                                                + VV10 (b = 6.0, C = 0.01).  Same skeleton as omega-B97 above with a two-variable
+                                                power series per channel, sum_ij c_ij w^i u^j, in u = gamma s^2 / (1 + gamma s^2)
+                                                and the kinetic-energy variable w = (t - 1) / (t + 1), t = tau_UEG / tau
+                                                (per spin channel; opposite spin: averages of s^2 and t).  libxc
+                                                HYB_MGGA_XC_WB97M_V; reference energy -76.4334218842 (tests/test_dft.py:105-109) --
+                                                the number that pins the tau branch of rho / V_xc AND VV10 (nr_nlc_vxc).
 Only zeta = 0 is needed (closed shells).  The potentials are obtained by COMPLEX-STEP differentiation of rho * e_xc:
 d f / d x = Im f(x + i h) / h with h = 1e-30 is exact to rounding for the analytic expressions above, so no derivative
 formula is written down (and none can be wrong).  ``eval_xc_eff`` returns what PySCF's ``NumInt.eval_xc_eff`` returns for
 deriv = 1: ``exc[ngrids]`` (energy per particle) and ``vxc[nvar, ngrids]`` = d(rho e_xc) / d(rho, grad rho) with nvar = 1
-(LDA) or 4 (GGA; components 1..3 = 2 v_sigma grad rho).
+(LDA), 4 (GGA; components 1..3 = 2 v_sigma grad rho) or 5 (meta-GGA; component 4 = d / d tau, tau = 1/2 sum |grad psi|^2).
 """
 import numpy as np
 
@@ -139,6 +147,31 @@ def wb97_xc(rho, sigma, omega=0.4):
     return (ex + ec) / rho
 
 
+def wb97mv_xc(rho, sigma, tau, omega=0.3):
+    """Semilocal part of omega-B97M-V, energy per particle, closed shell (tau = 1/2 sum_i |grad psi_i|^2 over both spins)."""
+    # (coefficient, power of w, power of u)
+    cx = ((0.85, 0, 0), (1.007, 0, 1), (0.259, 1, 0))
+    css = ((0.443, 0, 0), (-1.437, 0, 4), (-4.535, 1, 0), (-3.39, 2, 0), (4.278, 4, 3))
+    cos_ = ((1.000, 0, 0), (1.358, 1, 0), (2.924, 2, 0), (-8.812, 2, 1), (-1.39, 6, 0), (9.142, 6, 1))
+    gx, gss, gos = 0.004, 0.2, 0.006
+    rs_ = 0.5 * rho                                             # spin density
+    s2 = 0.25 * sigma / rs_ ** (8.0 / 3.0)                      # |grad rho_s|^2 / rho_s^(8/3)
+    ts = 0.5 * tau / rs_ ** (5.0 / 3.0)                         # tau_s / rho_s^(5/3)
+    kc = 0.3 * (6.0 * np.pi ** 2) ** (2.0 / 3.0)                # tau_UEG,s / rho_s^(5/3)
+    w = (kc - ts) / (kc + ts)                                   # = (t - 1) / (t + 1), t = tau_UEG / tau; closed shell: w_os = w_s
+
+    def series(c, g):
+        u = g * s2 / (1.0 + g * s2)
+        return sum(cf * w ** i * u ** j for cf, i, j in c)
+    kf = (6.0 * np.pi ** 2 * rs_) ** (1.0 / 3.0)
+    ex_lsda = -1.5 * (3.0 / (4.0 * np.pi)) ** (1.0 / 3.0) * rs_ ** (4.0 / 3.0)
+    ex = 2.0 * ex_lsda * _attenuation(omega / (2.0 * kf)) * series(cx, gx)
+    ec_ss = rs_ * pw92_c_ferro(rs_)
+    ec_ab = rho * pw92_c(rho) - 2.0 * ec_ss
+    ec = 2.0 * ec_ss * series(css, gss) + ec_ab * series(cos_, gos)
+    return (ex + ec) / rho
+
+
 _BETA = 0.06672455060314922
 _GAMMA = (1.0 - np.log(2.0)) / np.pi ** 2
 
@@ -167,25 +200,38 @@ FUNCTIONALS = {
     "pbe": ("GGA", lambda r, s: pbe_x(r, s) + pbe_c(r, s)),
     "b3lyp": ("GGA", lambda r, s: 0.08 * slater_x(r) + 0.72 * b88_x(r, s) + 0.81 * lyp_c(r, s) + 0.19 * vwn_rpa_c(r)),
     "wb97": ("GGA", lambda r, s: wb97_xc(r, s)),
+    "wb97m-v": ("MGGA", lambda r, s, t: wb97mv_xc(r, s, t)),
 }
+_ALIASES = {"hyb_gga_xc_wb97": "wb97", "hyb_mgga_xc_wb97m_v": "wb97m-v", "wb97m_v": "wb97m-v", "wb97mv": "wb97m-v"}
+
+
+def _key(xc_code):
+    k = xc_code.lower().replace(" ", "")
+    return _ALIASES.get(k, k)
 
 # (omega, alpha, hyb) as pyscf's ni.rsh_and_hybrid_coeff returns them: long-range HF fraction alpha at range separation omega,
 # short-range / global HF fraction hyb
-HYBRID = {"b3lyp": (0.0, 0.0, 0.2), "wb97": (0.4, 1.0, 0.0)}
+HYBRID = {"b3lyp": (0.0, 0.0, 0.2), "wb97": (0.4, 1.0, 0.0), "wb97m-v": (0.3, 1.0, 0.15)}
+# VV10 parameters ((b, C), factor) as pyscf's ni.nlc_coeff returns them
+NLC = {"wb97m-v": (((6.0, 0.01), 1.0),)}
 
 
 def rsh_and_hybrid_coeff(xc_code):
-    return HYBRID.get(xc_code.lower().replace(" ", ""), (0.0, 0.0, 0.0))
+    return HYBRID.get(_key(xc_code), (0.0, 0.0, 0.0))
+
+
+def nlc_coeff(xc_code):
+    return NLC.get(_key(xc_code), ())
 
 
 def xc_type(xc_code):
-    return FUNCTIONALS[xc_code.lower().replace(" ", "")][0]
+    return FUNCTIONALS[_key(xc_code)][0]
 
 
 def eval_xc_eff(xc_code, rho, rho_floor=1e-14):
     """(exc[ngrids], vxc[nvar, ngrids]) for rho[ngrids] (LDA) or rho[4, ngrids] (GGA); points below ``rho_floor`` give zero
     (libxc's density threshold has the same role)."""
-    kind, f = FUNCTIONALS[xc_code.lower().replace(" ", "")]
+    kind, f = FUNCTIONALS[_key(xc_code)]
     rho = np.asarray(rho, dtype=np.float64)
     r = rho if rho.ndim == 1 else rho[0]
     ok = r > rho_floor
@@ -196,6 +242,15 @@ def eval_xc_eff(xc_code, rho, rho_floor=1e-14):
         return exc, v.reshape(1, -1)
     g = rho[1:4]
     sg = np.where(ok, np.maximum((g * g).sum(axis=0), 1e-40), 1e-40)     # (B88 is a function of sqrt(sigma): keep the step off the branch point)
+    if kind == "MGGA":
+        # tau >= tau_W = sigma / (8 rho) for any N-representable density; the floor only keeps dead points finite
+        tt = np.where(ok, np.maximum(rho[4], 1e-40), 1.0)
+        exc = np.where(ok, f(rr, sg, tt), 0.0)
+        vxc = np.zeros((5, r.size))
+        vxc[0] = np.where(ok, np.imag((rr + 1j * _H) * f(rr + 1j * _H, sg, tt)) / _H, 0.0)
+        vxc[1:4] = np.where(ok, 2.0 * np.imag(rr * f(rr, sg + 1j * _H, tt)) / _H, 0.0) * g
+        vxc[4] = np.where(ok, np.imag(rr * f(rr, sg, tt + 1j * _H)) / _H, 0.0)
+        return exc, vxc
     exc = np.where(ok, f(rr, sg), 0.0)
     vrho = np.imag((rr + 1j * _H) * f(rr + 1j * _H, sg)) / _H
     vsig = np.imag(rr * f(rr, sg + 1j * _H)) / _H

@@ -262,13 +262,15 @@ class _ClosedFormLibXC:
 
     @staticmethod
     def is_nlc(xc_code):
-        return False
+        from oracle import xc
+        return bool(xc.nlc_coeff(xc_code))
 
 
 class ClosedFormNumInt:
     """Stand-in for ``pyscf.dft.numint.NumInt`` + libxc for the functionals whose energies the reference's tests hold and that
-    have closed forms ("lda,vwn5", "pbe", "b3lyp", "wb97": jqc/pyscf/tests/test_dft.py:75-103,110-114): oracle/xc.py behind the
-    ``eval_xc_eff`` signature (NumPy in, NumPy out, like a plain CPU PySCF NumInt)."""
+    have closed forms ("lda,vwn5", "pbe", "b3lyp", "wb97", "wb97m-v": jqc/pyscf/tests/test_dft.py:75-114): oracle/xc.py behind
+    the ``eval_xc_eff`` signature (NumPy in, NumPy out, like a plain CPU PySCF NumInt); ``nlc_coeff`` carries the VV10
+    parameters of a functional that has a non-local part."""
     libxc = _ClosedFormLibXC()
 
     def _xc_type(self, xc_code):
@@ -285,7 +287,8 @@ class ClosedFormNumInt:
         return xc.rsh_and_hybrid_coeff(xc_code)
 
     def nlc_coeff(self, xc_code):
-        return ()
+        from oracle import xc
+        return xc.nlc_coeff(xc_code)
 
 
 class Grids:
@@ -300,10 +303,10 @@ class RKS(RHF):
     """Minimal restricted Kohn-Sham driver with the attribute surface ``apply`` patches on an RKS object
     (``_numint``, ``grids``, ``xc``, ``get_j/get_k/get_jk``, ``get_veff`` returning a tagged potential)."""
 
-    def __init__(self, mol, hcore, ovlp, grids, xc="slater", numint=None, int1e=None):
+    def __init__(self, mol, hcore, ovlp, grids, xc="slater", numint=None, int1e=None, nlcgrids=None):
         super().__init__(mol, hcore, ovlp, int1e)
         self.grids = grids
-        self.nlcgrids = grids
+        self.nlcgrids = grids if nlcgrids is None else nlcgrids
         self.xc = xc
         self.nlc = ""
         self._numint = numint or SlaterNumInt()
@@ -313,7 +316,8 @@ class RKS(RHF):
         return name in ("RKS", "RHF", "SCF", "KohnShamDFT")
 
     def do_nlc(self):
-        return False
+        """pyscf.dft.rks.KohnShamDFT.do_nlc: does the functional (or ``self.nlc``) carry a VV10 part?"""
+        return bool(self._numint.nlc_coeff(self.xc)) if hasattr(self._numint, "nlc_coeff") else False
 
     def get_j(self, mol=None, dm=None, hermi=1, **kw):
         return self.get_jk(mol, dm, hermi, with_k=False, **kw)[0]

@@ -276,6 +276,44 @@ def test_reference_dft_energies_through_apply(kats, xc_code, e_ref):
     assert abs(e64 - e_ref) < 1e-6, e64 - e_ref      # all-FP64 grid path: the CPU oracle's bar (tests/test_dft_known_answers.py)
 
 
+def test_reference_wb97mv_energy_through_apply_pins_tau_and_vv10(kats):
+    """jqc/pyscf/tests/test_dft.py:105-109 ("HYB_MGGA_XC_WB97M_V", -76.4334218842, tolerance 1e-5 there; BASELINE config 4's
+    functional) through ``apply()``: the meta-GGA instantiations of rho_mfma_kernel / vxc_mfma_kernel (tau branch of reference
+    eval_rho.cu:328-377 / eval_vxc.cu:373-383), ``nr_nlc_vxc`` on its own NLC grid (pyscf/rks.py:670-712) with the packed-FP32
+    vv10_kernel (vv10.cu:89-107), and the range-separated get_veff with a short-range AND a long-range exact-exchange fraction
+    (full-range K scaled by 0.15 + long-range K-only build scaled by 0.85, omega = 0.3).  The functional is the closed form of
+    oracle/xc.py standing in for libxc; the CPU oracle reproduces the same number to 4e-8 (tests/test_dft_known_answers.py)."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.gto import mole
+    from joltqc_amd.gto.grids import Grids
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from standin_scf import RKS, ClosedFormNumInt
+    from oracle import dense
+    mol = mole.Mole(atom=kats["h2o_def2tzvpp"]["atom"], basis="def2-tzvpp")
+    S, T, V = dense.int1e_mol(BasisLayout.from_mol(mol), mol)
+    e_ref = -76.4334218842
+
+    def run(cfg):
+        mf = RKS(mol, T + V, S, Grids(mol, 90, 24), xc="HYB_MGGA_XC_WB97M_V", numint=ClosedFormNumInt(), nlcgrids=Grids(mol, 50, 14))
+        assert mf.do_nlc()
+        mf = jp.apply(mf, cfg)
+        patched, n_nlc = mf._numint.nr_nlc_vxc, [0]
+
+        def counted(*a, **k):
+            n_nlc[0] += 1
+            return patched(*a, **k)
+        mf._numint.nr_nlc_vxc = counted
+        e = mf.kernel()
+        assert mf.converged and n_nlc[0] >= mf.cycles, "nr_nlc_vxc of apply() was not on the path"
+        return e, mf
+    e, mf = run(None)                                 # default windows (FP32 MFMA band, FP32 VV10 inner loop)
+    assert abs(e - e_ref) < 1e-5, e - e_ref
+    cfg = jp.get_default_config()
+    cfg["dft"] = {"cutoff_fp32": 1e-13, "cutoff_fp64": 1e-13}
+    e64, _ = run(cfg)
+    assert abs(e64 - e_ref) < 1e-6, e64 - e_ref
+
+
 def test_build_grids_through_apply_on_a_generated_becke_grid():
     """A17 (reference rks.py:100-177): apply() replaces ``grids.build``; on first use the object's own generator runs (here the
     Becke generator of joltqc_amd/gto/grids.py standing in for PySCF's), the result is sorted into 1-Bohr boxes and padded to a

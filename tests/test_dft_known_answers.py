@@ -1,7 +1,7 @@
 """The reference's own DFT energies pin the grid-path oracle: H2O / def2-TZVPP with "LDA,vwn5", "PBE", "B3LYP" (spherical and
-Cartesian) and "HYB_GGA_XC_WB97" (/root/reference/jqc/pyscf/tests/test_dft.py:75-114: -75.9046410402, -76.3800182418,
--76.4666495594, -76.4672144985, -76.4486274326; tolerance 1e-5 there): LDA, GGA, global-hybrid (exact exchange) and
-range-separated-hybrid (long-range exchange, omega = 0.4) Kohn-Sham paths.
+Cartesian), "HYB_GGA_XC_WB97" and "HYB_MGGA_XC_WB97M_V" (/root/reference/jqc/pyscf/tests/test_dft.py:75-114: -75.9046410402,
+-76.3800182418, -76.4666495594, -76.4672144985, -76.4486274326, -76.4334218842; tolerance 1e-5 there): LDA, GGA, global-hybrid
+(exact exchange), range-separated-hybrid (long-range exchange, omega = 0.4) and meta-GGA + VV10 Kohn-Sham paths.
 
 Everything on the path is this repo's CPU restatement: oracle/dft.py (AO values, rho, V_xc), oracle/xc.py (closed-form
 functionals), oracle/rks.py (nr_rks / get_veff), the Rys J oracle, the MD one-electron integrals and the Becke grid
@@ -17,19 +17,24 @@ from joltqc_amd.pyscf.basis import BasisLayout
 from oracle import dense, rks
 from standin_scf import RKS, Grids
 
-E_REF = {"lda,vwn5": -75.9046410402, "pbe": -76.3800182418, "b3lyp": -76.4666495594, "wb97": -76.4486274326}
+E_REF = {"lda,vwn5": -75.9046410402, "pbe": -76.3800182418, "b3lyp": -76.4666495594, "wb97": -76.4486274326,
+         "wb97m-v": -76.4334218842}
 
 
-def oracle_rks_energy(kats, xc_code, nrad, ntheta, cart=False):
+def oracle_rks_energy(kats, xc_code, nrad, ntheta, cart=False, nlc_grid=None):
     mol = mole.Mole(atom=kats["h2o_def2tzvpp"]["atom"], basis="def2-tzvpp", cart=cart)
     lay = BasisLayout.from_mol(mol)
     S, T, V = dense.int1e_mol(lay, mol)
     q = dense.canonical_quartets(lay)
     g = G.Grids(mol, nrad=nrad, ntheta=ntheta).build()
     mf = RKS(mol, T + V, S, Grids(g.coords, g.weights), xc=xc_code)
+    if nlc_grid is not None:
+        gn = G.Grids(mol, nrad=nlc_grid[0], ntheta=nlc_grid[1]).build()
+        nlc_grid = (gn.coords, gn.weights)
     mf.get_veff = rks.make_get_veff(lay, g.coords, g.weights, xc_code,
                                     lambda dm: dense.get_jk(lay, dm, 1, with_k=False, quartets=q)[0],
-                                    lambda dm, omega: dense.get_jk(lay, dm, 1, with_j=False, quartets=q, omega=omega)[1])
+                                    lambda dm, omega: dense.get_jk(lay, dm, 1, with_j=False, quartets=q, omega=omega)[1],
+                                    nlc_grid=nlc_grid)
     e = mf.kernel()
     assert mf.converged
     return e, mf.get_veff.stats["nelec"]
@@ -51,3 +56,16 @@ def test_h2o_def2tzvpp_b3lyp_cartesian_energy_matches_the_reference(kats):
     """test_dft.py:110-114 (mol_cart): -76.4672144985 -- hybrid exchange, GGA and the Cartesian d / f shells together."""
     e, nelec = oracle_rks_energy(kats, "b3lyp", 90, 24, cart=True)
     assert abs(nelec - 10.0) < 1e-7 and abs(e + 76.4672144985) < 1e-6, (e, nelec)
+
+
+def test_h2o_def2tzvpp_wb97mv_energy_pins_the_tau_branch_and_vv10(kats):
+    """test_dft.py:105-109 ("HYB_MGGA_XC_WB97M_V": -76.4334218842; BASELINE config 4's functional and the only one the reference
+    publishes timings for): the meta-GGA branch of rho / V_xc (tau = 1/2 sum D grad phi . grad phi and its potential term,
+    reference eval_rho.cu:328-377, eval_vxc.cu:373-383), VV10 (vv10.cu:89-107 + the pre / post algebra of backend/rks.py:542-715
+    through nr_nlc_vxc, pyscf/rks.py:670-712) and the range-separated get_veff with BOTH a short-range and a long-range exact-
+    exchange fraction (0.15 / 1.0, omega = 0.3) in one number.  The functional is the published closed form (oracle/xc.py).
+    Grids refined until stable: main (60, 16) -> (90, 24) and NLC (40, 10) -> (50, 14) move the energy by 3e-7 / 1e-7 Eh; at
+    (60, 16) + (40, 10) the oracle sits 2.9e-7 Eh from the reference's number (which carries PySCF's own level-5 / level-2 grids)."""
+    e, nelec = oracle_rks_energy(kats, "wb97m-v", 60, 16, nlc_grid=(40, 10))
+    assert abs(nelec - 10.0) < 1e-6, nelec
+    assert abs(e - E_REF["wb97m-v"]) < 1e-6, e - E_REF["wb97m-v"]

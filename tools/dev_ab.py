@@ -5,7 +5,8 @@ per class on a large molecule.  The shipped sources and their verified code obje
   python tools/dev_ab.py build  <classes> <name=defs> [<name=defs> ...]     (CPU: compile into kcache_dev)
   python tools/dev_ab.py run    <classes> <name=defs> [...]                 (GPU box) -> gpurun_out/dev_ab_<tag>.json
 classes: comma list such as 2110,3120 or "tile1q" (every class the scheme table routes to the lane-per-quartet mode) or
-"all" (s..f).  defs example:  base=  qil=-DQIL=1  all="-DQIL=1 -DCORD=1".  JQC_AB_ALGO=<code> forces one variant code.
+"all" (s..f).  defs example:  base=  qil=-DQIL=1  all="-DQIL=1 -DCORD=1".  JQC_AB_ALGO=<code> forces one variant code for every
+configuration; a configuration written  name=@<code>:<defs>  forces its own (e.g. quad=@0x1001022:).
 """
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +28,9 @@ def class_list(spec):
 
 def env_for(defs, classes):
     e = dict(os.environ)
+    if defs.startswith("@"):
+        code, defs = defs[1:].split(":", 1)
+        e["JQC_JK_ALGO"] = "v%d" % int(code, 0)
     e.update(JQC_KERNEL_SRC=DEV, JQC_EXTRA_DEFS=defs, JQC_TRUST_KERNELS="1", JQC_STREAMS="1",
              JQC_ONLY_CLASS=",".join("%d%d%d%d" % a for a in classes))
     if os.environ.get("JQC_AB_ALGO"):
