@@ -317,7 +317,8 @@ def main():
     from joltqc_amd.constants import tile_width
     from joltqc_amd.pyscf import jk as jkmod
     from joltqc_amd.pyscf.basis import BasisLayout
-    from joltqc_amd.roofline import FP64_VALU_PEAK_TFLOPS, quartet_bytes, quartet_flops
+    from joltqc_amd.roofline import (FP64_VALU_PEAK_MEASURED_BY_WAVES, FP64_VALU_PEAK_MEASURED_TFLOPS, FP64_VALU_PEAK_TFLOPS,
+                                     quartet_bytes, quartet_flops)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -388,6 +389,18 @@ def main():
         tm.setdefault(ang, []).append(e0.elapsed_time(e1))
     tm = {a: float(np.mean(v)) for a, v in tm.items()}
     serial_ms = sum(tm.values())
+    # what a rank does NOT shard: everything of a call but the class kernels -- D into the internal order (two GEMMs), shell-block
+    # maxima + their logarithm, the plan lookup and the launch loop, zeroing the Fock buffers, the epilogue (transposes, two GEMMs per
+    # matrix back to the molecule's order).  Measured by a call whose class filter rejects every class; at N ranks this time stays
+    # while the kernel time divides, so it bounds the scaling curve: T(N) ~ kernel_sum / N x imbalance + host_serial + all-reduce.
+    get_jk.set_probe(None)
+    get_jk(mol, dm, hermi=1, _classes=lambda a: False)
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    for _ in range(3):
+        get_jk(mol, dm, hermi=1, _classes=lambda a: False)
+    torch.cuda.synchronize()
+    host_serial_ms = (time.perf_counter() - th) / 3 * 1e3
     per_rank = None
     if world > 1:
         # diagnosability of the scaling curve: what every rank did -- its kernels' serial time, its quartets, the one Fock
@@ -431,16 +444,31 @@ def main():
             "roofline": {"bound": "valu_fp64", "kernel": kname, "selected_by": "largest measured launch time (HIP events, serial streams)",
                          "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VALU_PEAK_TFLOPS,
+                         "peak_measured": FP64_VALU_PEAK_MEASURED_TFLOPS, "frac_of_measured_peak": achieved / FP64_VALU_PEAK_MEASURED_TFLOPS,
+                         "peak_measured_by_waves_per_simd": FP64_VALU_PEAK_MEASURED_BY_WAVES,
+                         "peak_note": "peak = datasheet FP64 vector rate; peak_measured = v_fma_f64 micro-benchmark on this pool's MI355X "
+                                      "(tools/micro/fp64_fma_peak.hip, profiles/r05_fp64_fma_peak_microbench.json)",
                          "kernel_ms": kern_ms, "kernel_gflop": flops_by_ang.get(dom, 0) / 1e9,
                          "kernel_quartets": count_by_ang.get(dom, 0),
                          "algorithmic_bytes": bytes_by_ang.get(dom, 0), "traffic": None,
                          "whole_path": {"achieved": flops_all * steps / dt / 1e12,
                                         "frac": flops_all * steps / dt / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                        "frac_of_measured_peak": flops_all * steps / dt / 1e12 / FP64_VALU_PEAK_MEASURED_TFLOPS,
                                         "serial_kernel_sum_ms": serial_ms, "classes": len(tm)},
                          "best_kernel": {"kernel": "%d%d%d%d" % best,
                                          "achieved": flops_by_ang.get(best, 0) / tm[best] / 1e9,
                                          "frac": flops_by_ang.get(best, 0) / tm[best] / 1e9 / FP64_VALU_PEAK_TFLOPS}},
         }
+        ar_bytes = 2 * layout.nao * layout.nao * 8
+        out["host_serial_ms"] = host_serial_ms
+        out["scaling_model"] = {
+            "host_serial_ms": host_serial_ms, "kernel_sum_ms": serial_ms, "allreduce_bytes": ar_bytes,
+            "form": "T(N) = kernel_sum_ms / N x imbalance + host_serial_ms + allreduce_ms(N)",
+            # ring all-reduce over xGMI: 2 (N - 1) / N x bytes per rank over one ~153 GB/s link direction at 70 % efficiency
+            "predicted_ms": {str(n): round(serial_ms / n * 1.1 + host_serial_ms + (0.0 if n == 1 else 2.0 * (n - 1) / n * ar_bytes / (0.7 * 153e9) * 1e3), 1)
+                             for n in (1, 2, 4, 8)},
+            "assumptions": "imbalance 1.10 (LPT split, tests/test_sharding.py: <= 10 %), ring all-reduce at 70 % of one 153 GB/s xGMI link "
+                           "direction (MI355X_MICROARCH.md); a prediction until an N > 1 node runs the bench"}
         if per_rank is not None:
             out["per_rank"] = per_rank
         tr = committed_traffic(kname) if args.workload == DEFAULT_WORKLOAD else None

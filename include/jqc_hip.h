@@ -152,6 +152,18 @@ int jqc_shell_block_max(const double* mat_d, int n_dm, int nao, const int32_t* a
 int jqc_pair_table(const double* basis_d, const uint32_t* tpair_sh_d, const uint32_t* tpair_wij_d,
                    const uint32_t* pp_off_d, int npairs, double* out_d, void* stream);
 
+/* Scalar ECP integrals (replaces the kernel launches of the reference's get_ecp,
+ * /root/reference/jqc/backend/ecp.py:1371-1503 -> ecp/ecp_type1.cu, ecp_type2.cu): for every task {ish, jsh, k} (ish <= jsh, ECP atom k)
+ *   mat[ao_i.., ao_j..] += <i| U_L |j> + sum_l <i| U_l P_l |j>   (and the transposed block when ish != jsh), internal Cartesian AOs.
+ * basis_d: packed shell rows (12 doubles, as every kernel); ecp_xyz_d [natm_ecp][3]; terms of ECP atom k =
+ * ecp_terms_d[ecp_loc_d[k] .. ecp_loc_d[k + 1]) x {l (-1 = local channel), radial power n, zeta, coefficient}, i.e. the rows of
+ * mol._ecpbas flattened per primitive; rgrid_d / wgrid_d: nr radial quadrature points (r, dr weight, WITHOUT r^2) on (0, inf);
+ * ylm_d [25][15]: Cartesian monomial coefficients (libcint order) of the orthonormal real spherical harmonics l <= 4.
+ * Shells and projectors up to l = 4, FP64 only (the reference's ECP kernels are FP64 only too, jqc/pyscf/ecp.py:51-53). */
+int jqc_ecp_scalar(const double* basis_d, int nao, const int32_t* tasks_d, int ntasks, const double* ecp_xyz_d, const int32_t* ecp_loc_d,
+                   const double* ecp_terms_d, const double* rgrid_d, const double* wgrid_d, int nr, const double* ylm_d, double* mat_d,
+                   void* stream);
+
 /* One-electron integrals (overlap S, kinetic T, nuclear attraction V) of n shell pairs (ish << 16 | jsh, ish >= jsh) in the
  * internal Cartesian basis, [nao, nao] each, both triangles written.  atoms_d = [x, y, z, Z] per nucleus (Bohr).  The
  * reference takes these from PySCF/libcint on the CPU (mf.get_hcore / get_ovlp); SURVEY.md 8f row 1. */

@@ -93,6 +93,21 @@ constexpr int NQ = TSI * TSJ * TSK * TSL;
                     // matrices of a call in groups of NDM; D and Fock tiles of a group live in LDS side by side.  Reference:
                     // every density matrix is contracted against the same integral block (jk/1q1t.cu:423-638, 1qnt.cu:488).
 #endif
+#ifndef QUAD
+#define QUAD 0      // lane-per-quartet mode for classes with a p shell (index X = the last p among l, k, j, i): a quartet is worked on by
+                    // ONE QUAD of lanes (DPP quad = 4 consecutive lanes), 64 quartets per pass of a workgroup.  Lanes c = 0, 1, 2 of
+                    // the quad own Cartesian axis c: lane c runs the transfer + horizontal recurrences of axis c only (a third of
+                    // the recurrence work, nothing redundant) and owns the integrals whose X component is p_c, i.e. a third of the
+                    // integral block.  Such an integral is  g_c[X-power 1] * g_(c+1)[X-power 0] * g_(c+2)[X-power 0]:  the lane needs its
+                    // own 1-D array and the X-power-0 HALF of its two neighbours' arrays, which it fetches register to register with
+                    // two quad-permute DPP moves per double (no LDS array, no barrier).  Every lane enumerates its block in axes
+                    // ROTATED so that its own axis comes first (then the code is the same for the three lanes); the rotated
+                    // component labels are turned back into AO offsets by compile-time permutation tables selected by c.
+                    // Each lane evaluates ONE Rys root per primitive combination (lane r of the quad: root r, so the fourth lane
+                    // is of use when there are four roots) and the root in work is broadcast inside the quad.  Purpose: the
+                    // 100-180-integral classes fit 256 registers (no AGPR copies, second workgroup per CU); price: the fourth
+                    // lane idles otherwise, and blocks that do not carry X are added to the LDS tiles by three lanes.
+#endif
 #ifndef ORED
 #define ORED 0      // row-lane mode with the j components in registers (CJR): the three outputs that are summed over the bra
                     // component i -- J_kl, K_jk, K_jl, i.e. over the LANES of a quartet -- are not added to the LDS Fock tiles by
@@ -347,6 +362,48 @@ __device__ __forceinline__ void rys_root_pk(v2f x, const v2f theta, const float 
         const float lr = (float)large[2 * r], lw = (float)large[2 * r + 1];
         if (big0) { const float isx = __builtin_amdgcn_rsqf(x.x); root.x = lr * isx * isx * tf.x; weight.x = lw * isx * stf.x; }
         if (big1) { const float isx = __builtin_amdgcn_rsqf(x.y); root.y = lr * isx * isx * tf.y; weight.y = lw * isx * stf.y; }
+    }
+}
+#endif
+
+#if QUAD
+// split index X and the rotated-component -> AO-component tables
+constexpr int XS = LL == 1 ? 3 : LK == 1 ? 2 : LJ == 1 ? 1 : LI == 1 ? 0 : -1;
+static_assert(XS >= 0, "QUAD: the class needs a p shell");
+static_assert(TILE_1Q && !MIXED && NROOTS <= 4, "QUAD: lane-per-quartet builds up to four Rys roots");
+constexpr int NXI = XS == 0 ? 1 : NFI, NXJ = XS == 1 ? 1 : NFJ, NXK = XS == 2 ? 1 : NFK, NXL = XS == 3 ? 1 : NFL;
+constexpr int NINTQ = NXI * NXJ * NXK * NXL;              // integrals per lane
+constexpr int GS_X = XS == 0 ? GS_I : XS == 1 ? GS_J : XS == 2 ? GS_K : GS_L;
+// component n of a shell of angular momentum l, read with the axes rotated by c (own axis first): exponents (p, q, r) on
+// (a0, a1, a2) = (c, c+1, c+2) mod 3  ->  index of the Cartesian component with those exponents on (x, y, z)
+constexpr int rot_comp(const int l, const int c, const int n)
+{
+    const CartPow p = cart_pow(l, n);
+    const int ex = c == 0 ? p.x : c == 1 ? p.z : p.y;
+    const int ey = c == 0 ? p.y : c == 1 ? p.x : p.z;
+    return (l - ex) * (l - ex + 1) / 2 + (l - ex - ey);
+}
+// quad permutes (DPP): lane c of a quad reads lane (c + 1) % 3 / (c + 2) % 3 (lane 3 mirrors lane 0)
+#define DPP_ROT1 0x49   /* quad_perm:[1,2,0,1] */
+#define DPP_ROT2 0x92   /* quad_perm:[2,0,1,2] */
+template <int CTRL> __device__ __forceinline__ double dpp_quad(const double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_quad(const float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// value of lane r of the quad (r wave-uniform)
+__device__ __forceinline__ real quad_bcast(const real v, const int r)
+{
+    switch (r) {
+    case 0: return dpp_quad<0x00>(v);
+    case 1: return dpp_quad<0x55>(v);
+    case 2: return dpp_quad<0xaa>(v);
+    default: return dpp_quad<0xff>(v);
     }
 }
 #endif
@@ -969,6 +1026,190 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #else
 #define DLD(x) (x)
 #endif
+#if QUAD
+            // ---------------- one quartet per QUAD of lanes (see QUAD above)
+            {
+            const int qc = tid & 3;                        // lane of the quad
+            const int ax0 = qc == 3 ? 0 : qc;              // own axis (lane 3: a copy of lane 0 that adds nothing)
+            const bool q_on = qc < 3;
+            const int rme = qc < NROOTS ? qc : NROOTS - 1; // the Rys root this lane evaluates
+            for (int q1 = tid >> 2; q1 < nact; q1 += TBLOCK / 4) {
+                const int qe = s_act[q1];
+                const int ks = NKS > 1 ? qe >> KS_SHIFT : 0, qd = NKS > 1 ? qe & ((1 << KS_SHIFT) - 1) : qe;
+                const int a = qd % TSI, b = (qd / TSI) % TSJ, d = (qd / (TSI * TSJ)) % TSL, c = QC(qd / (TSI * TSJ * TSL), a, b, d);
+                int kshb = ksh0s[0], lshb = lsh0s[0];
+#pragma unroll
+                for (int u = 1; u < NKS; u++)
+                    if (ks == u) { kshb = ksh0s[u]; lshb = lsh0s[u]; }
+                const int ish = ish0 + a, jsh = jsh0 + b, ksh = kshb + c, lsh = lshb + d;
+                const real* bi = sBas + a * BASIS_STRIDE;
+                const real* bj = sBas + OFF_J + b * BASIS_STRIDE;
+                const real* bk = sBas + OFF_K + ks * KSTR + c * BASIS_STRIDE;
+                const real* bl = sBas + OFF_L + ks * KSTR + d * BASIS_STRIDE;
+                const real* pb = sPB + (a * TSJ + b) * 27;
+                const real* pk = sPK + (ks * TSK * TSL + c * TSL + d) * 27;
+                // own-axis geometry only
+                const real ri_o = bi[ax0], rk_o = bk[ax0];
+                const real rij_o = bj[ax0] - ri_o, rkl_o = bl[ax0] - rk_o;
+                real fac = real(34.98683665524972497);
+                if (ish == jsh) fac *= real(0.5);
+                if (ksh == lsh) fac *= real(0.5);
+                if (ish == ksh && jsh == lsh) fac *= real(0.5);
+                real I[NINTQ];
+#pragma unroll
+                for (int n = 0; n < NINTQ; n++) I[n] = 0;
+                for (int kp = 0; kp < npk; kp++)
+                for (int lp = 0; lp < npl; lp++) {
+                    const real ckcl = pk[(kp * 3 + lp) * 3], inv_akl = pk[(kp * 3 + lp) * 3 + 1], akl = pk[(kp * 3 + lp) * 3 + 2];
+                    const real al_akl = bl[5 + 2 * lp] * inv_akl;
+                    const real rqc_o = rkl_o * al_akl;
+                    for (int ip = 0; ip < npi; ip++)
+                    for (int jp = 0; jp < npj; jp++) {
+                        const real inv_aij = pb[(ip * 3 + jp) * 3 + 1], aij = pb[(ip * 3 + jp) * 3 + 2];
+                        const real aj_aij = bj[5 + 2 * jp] * inv_aij;
+                        const real cicj = fac * pb[(ip * 3 + jp) * 3];
+                        const real rpa_o = rij_o * aj_aij;
+                        const real rpq_o = rpa_o + ri_o - rqc_o - rk_o;
+                        const real s2 = rpq_o * rpq_o;
+                        const real rr = s2 + dpp_quad<DPP_ROT1>(s2) + dpp_quad<DPP_ROT2>(s2);     // |P - Q|^2 from the three axis lanes
+                        const real sinv = fast_rsqrt(aij + akl);
+                        const real inv = sinv * sinv;
+                        const real theta = aij * akl * inv;
+                        const real gy0 = cicj * inv_aij * inv_akl * sinv;
+                        real t2m, wtm;
+                        rys_root_one(rr, theta, omega, rme, cheb_tab, rys_large, t2m, wtm);
+#pragma clang loop unroll(disable)
+                        for (int ir = 0; ir < NROOTS; ir++) {
+                            const real t2 = quad_bcast(t2m, ir), wt = quad_bcast(wtm, ir);
+                            const real rt_aa = t2 * inv;
+                            const real rt_aij = rt_aa * akl, rt_akl = rt_aa * aij;
+                            const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
+                            const real b01 = real(0.5) * inv_akl * (real(1) - rt_akl);
+                            const real b00 = real(0.5) * rt_aa;
+                            const real seed = ax0 == 0 ? ckcl : ax0 == 1 ? gy0 : wt;
+                            real g0[GSIZE], g1[GSIZE], g2[GSIZE];
+                            axis_integrals(seed, rpa_o - rt_aij * rpq_o, rqc_o + rt_akl * rpq_o, b10, b01, b00, rij_o, rkl_o, g0);
+                            // X-power-0 halves of the two neighbouring axes
+#pragma unroll
+                            for (int e = 0; e < GSIZE; e++)
+                                if ((e / GS_X) % 2 == 0) { g1[e] = dpp_quad<DPP_ROT1>(g0[e]); g2[e] = dpp_quad<DPP_ROT2>(g0[e]); }
+#pragma unroll
+                            for (int i = 0; i < NXI; i++)
+#pragma unroll
+                            for (int j = 0; j < NXJ; j++)
+#pragma unroll
+                            for (int k = 0; k < NXK; k++)
+#pragma unroll
+                            for (int l = 0; l < NXL; l++) {
+                                const int e0 = TI.x[i] * GS_I + TJ.x[j] * GS_J + TK.x[k] * GS_K + TL.x[l];
+                                const int e1 = TI.y[i] * GS_I + TJ.y[j] * GS_J + TK.y[k] * GS_K + TL.y[l];
+                                const int e2 = TI.z[i] * GS_I + TJ.z[j] * GS_J + TK.z[k] * GS_K + TL.z[l];
+                                I[((i * NXJ + j) * NXK + k) * NXL + l] += g0[e0] * g1[e1] * g2[e2];
+                            }
+                        }
+                    }
+                }
+                // ---- AO offsets of the rotated components: index X carries component ax0, the others the rotation table
+                int oi[NXI], oj[NXJ], ok[NXK], ol[NXL];
+#pragma unroll
+                for (int n = 0; n < NXI; n++) oi[n] = a * NFI + (XS == 0 ? ax0 : ax0 == 0 ? n : ax0 == 1 ? rot_comp(LI, 1, n) : rot_comp(LI, 2, n));
+#pragma unroll
+                for (int n = 0; n < NXJ; n++) oj[n] = b * NFJ + (XS == 1 ? ax0 : ax0 == 0 ? n : ax0 == 1 ? rot_comp(LJ, 1, n) : rot_comp(LJ, 2, n));
+#pragma unroll
+                for (int n = 0; n < NXK; n++) ok[n] = c * NFK + (XS == 2 ? ax0 : ax0 == 0 ? n : ax0 == 1 ? rot_comp(LK, 1, n) : rot_comp(LK, 2, n));
+#pragma unroll
+                for (int n = 0; n < NXL; n++) ol[n] = d * NFL + (XS == 3 ? ax0 : ax0 == 0 ? n : ax0 == 1 ? rot_comp(LL, 1, n) : rot_comp(LL, 2, n));
+                if (q_on) {
+#if NDM > 1
+#pragma unroll 1
+                for (int dmi = 0; dmi < NDM && dmi < ndm_grp; dmi++) {
+#else
+                {
+                constexpr int dmi = 0;
+#endif
+                const real* const qDij = sDij + dmi * (WJ * WI);
+                double* const qJij = sJij + dmi * ((TILE_1Q ? JREP : 1) * WJ * WI);
+                const real* qDkl = sDkl + (dmi * NKS + ks) * (WL * WK); const real* qDik = sDik + (dmi * NKS + ks) * (WI * WK);
+                const real* qDil = sDil + (dmi * NKS + ks) * (WI * WL); const real* qDjk = sDjk + (dmi * NKS + ks) * (WJ * WK);
+                const real* qDjl = sDjl + (dmi * NKS + ks) * (WJ * WL);
+                double* qJkl = sJkl + (dmi * NKS + ks) * (WL * WK); double* qKik = sKik + (dmi * NKS + ks) * (WI * WK);
+                double* qKil = sKil + (dmi * NKS + ks) * (WI * WL); double* qKjk = sKjk + (dmi * NKS + ks) * (WJ * WK);
+                double* qKjl = sKjl + (dmi * NKS + ks) * (WJ * WL);
+#if DO_J
+                {
+                    real jkl[NXK * NXL], dkl[NXK * NXL];
+#pragma unroll
+                    for (int k = 0; k < NXK; k++)
+#pragma unroll
+                        for (int l = 0; l < NXL; l++) { jkl[k * NXL + l] = 0; dkl[k * NXL + l] = qDkl[ol[l] * WK + ok[k]]; }
+#pragma unroll
+                    for (int i = 0; i < NXI; i++)
+#pragma unroll
+                        for (int j = 0; j < NXJ; j++) {
+                            const real dij = qDij[oj[j] * WI + oi[i]];
+                            real sj = 0;
+#pragma unroll
+                            for (int n = 0; n < NXK * NXL; n++) {
+                                const real v = I[(i * NXJ + j) * NXK * NXL + n];
+                                sj += v * dkl[n];
+                                jkl[n] += v * dij;
+                            }
+                            lds_add(&qJij[oj[j] * WI + oi[i]], (double)sj);
+                        }
+#pragma unroll
+                    for (int k = 0; k < NXK; k++)
+#pragma unroll
+                        for (int l = 0; l < NXL; l++) lds_add(&qJkl[ol[l] * WK + ok[k]], (double)jkl[k * NXL + l]);
+                }
+#endif
+#if DO_K
+                {
+                    real kjk[NXJ * NXK], kjl[NXJ * NXL], djk[NXJ * NXK], djl[NXJ * NXL];
+#pragma unroll
+                    for (int j = 0; j < NXJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NXK; k++) { kjk[j * NXK + k] = 0; djk[j * NXK + k] = qDjk[oj[j] * WK + ok[k]]; }
+#pragma unroll
+                        for (int l = 0; l < NXL; l++) { kjl[j * NXL + l] = 0; djl[j * NXL + l] = qDjl[oj[j] * WL + ol[l]]; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NXI; i++) {
+                        real kik[NXK], kil[NXL], dik[NXK], dil[NXL];
+#pragma unroll
+                        for (int k = 0; k < NXK; k++) { kik[k] = 0; dik[k] = qDik[oi[i] * WK + ok[k]]; }
+#pragma unroll
+                        for (int l = 0; l < NXL; l++) { kil[l] = 0; dil[l] = qDil[oi[i] * WL + ol[l]]; }
+#pragma unroll
+                        for (int j = 0; j < NXJ; j++)
+#pragma unroll
+                            for (int k = 0; k < NXK; k++)
+#pragma unroll
+                                for (int l = 0; l < NXL; l++) {
+                                    const real v = I[((i * NXJ + j) * NXK + k) * NXL + l];
+                                    kik[k] += v * djl[j * NXL + l];
+                                    kil[l] += v * djk[j * NXK + k];
+                                    kjk[j * NXK + k] += v * dil[l];
+                                    kjl[j * NXL + l] += v * dik[k];
+                                }
+#pragma unroll
+                        for (int k = 0; k < NXK; k++) lds_add(&qKik[oi[i] * WK + ok[k]], (double)kik[k]);
+#pragma unroll
+                        for (int l = 0; l < NXL; l++) lds_add(&qKil[oi[i] * WL + ol[l]], (double)kil[l]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NXJ; j++) {
+#pragma unroll
+                        for (int k = 0; k < NXK; k++) lds_add(&qKjk[oj[j] * WK + ok[k]], (double)kjk[j * NXK + k]);
+#pragma unroll
+                        for (int l = 0; l < NXL; l++) lds_add(&qKjl[oj[j] * WL + ol[l]], (double)kjl[j * NXL + l]);
+                    }
+                }
+#endif
+                }
+                }
+            }
+            }
+#else   // !QUAD
 #if QIL
             // strided read: lane l takes entry (l % QS) * qchunk + l / QS, so the QS = 4 neighbours of a lane group come from
             // four far-apart quarters of the queue (different ket slots when NKS > 1)
@@ -1350,6 +1591,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
                 STAMP(12);          // (diagnostic) contraction + LDS atomics of this batch
 }
+#endif  // QUAD
 #if MIXED
             // ---------------- FP32 phase of a MIXED build: TWO quartets per lane, every per-quartet quantity a 2-vector (component
             //                  x = queue entry 2p, y = entry 2p + 1 of the FP32 survivors, which grow downwards from the end of

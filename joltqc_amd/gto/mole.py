@@ -72,9 +72,10 @@ class Mole:
     """Minimal ``pyscf.gto.Mole`` look-alike (attributes only; integrals live elsewhere)."""
 
     def __init__(self, atom=None, basis="sto-3g", unit="angstrom", cart=False, charge=0, spin=0,
-                 verbose=0, **_ignored):
+                 verbose=0, ecp=None, **_ignored):
         self.atom = atom
         self.basis = basis
+        self.ecp = ecp                    # {symbol: NWChem-format text}, as pyscf.gto.M(ecp=...) takes it (gto/ecp.py)
         self.unit = unit
         self.cart = bool(cart)
         self.charge = charge
@@ -123,6 +124,10 @@ class Mole:
         self._atm = np.array(atm, dtype=np.int32).reshape(-1, ATM_SLOTS)
         self._bas = np.array(bas, dtype=np.int32).reshape(-1, BAS_SLOTS)
         self._env = np.array(env, dtype=np.float64)
+        self._ecpbas = np.zeros((0, 8), dtype=np.int32)
+        if self.ecp:
+            from . import ecp as _ecp
+            _ecp.attach(self, self.ecp)
         self._built = True
         return self
 

@@ -112,8 +112,11 @@ class IncrementPolicy:
     neither error shrinks with the increment, so over the 20-30 iterations of an SCF run they pile up (measured on 112 atoms /
     B3LYP / def2-SVP, profiles/r04_config3_scf_noise.txt: E_xc 3-5e-6 Eh off the from-scratch value, jittering by 1e-6 per
     iteration).  Rule: a full build when the largest element of the increment has fallen below ``SHRINK`` x its value at the last
-    full build, and after ``MAX_STEPS`` increments in a row -- 3-4 full builds per SCF run instead of one."""
+    full build, and after ``MAX_STEPS`` increments in a row -- 3-4 full builds per SCF run instead of one.  An increment that has
+    GROWN by ``GROW`` since the last full build is a restart (a second ``kernel()`` on the same closures, a new ``dm0``, a
+    stability follow-up: the density jumps while the reference value is that of a converged run) and is a full build as well."""
     SHRINK = 1e-3
+    GROW = 10.0
     MAX_STEPS = 12
 
     def __init__(self):
@@ -124,7 +127,7 @@ class IncrementPolicy:
 
     def full_build(self, ddmax):
         """``ddmax``: largest |element| of this call's increment.  True: build from the full matrix (and restart the count)."""
-        if self.ref is None or ddmax < self.SHRINK * self.ref or self.steps >= self.MAX_STEPS:
+        if self.ref is None or ddmax < self.SHRINK * self.ref or ddmax > self.GROW * self.ref or self.steps >= self.MAX_STEPS:
             self.ref, self.steps = max(float(ddmax), 1e-300), 0
             return True
         self.steps += 1

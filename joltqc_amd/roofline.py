@@ -12,6 +12,14 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X datasheet: 256 CU x 4 SIMD x 16 FP64 FMA
 FP64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: the datasheet's FP64 matrix rate equals the vector rate
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBS = 8000.0
+# Measured on an MI355X of this pool (tools/micro/fp64_fma_peak.hip, profiles/r05_fp64_fma_peak_microbench.json: chains of
+# independent v_fma_f64 / v_pk_fma_f32 / v_mfma_f64_16x16x4_f64, every CU, best of 1-8 waves per SIMD) -- SURVEY.md 8(d) asks
+# for the measured FMA rate as the denominator; the bench line carries both.  The FP64 vector rate depends on occupancy:
+# 59.2 TFLOP/s at one wave per SIMD, 68.6 at two, 75.3 at four, 76.2 at eight (an FMA's latency is not covered by one wave).
+FP64_VALU_PEAK_MEASURED_TFLOPS = 76.2
+FP64_VALU_PEAK_MEASURED_BY_WAVES = {1: 59.2, 2: 68.6, 4: 75.3, 8: 76.2}
+FP64_MFMA_PEAK_MEASURED_TFLOPS = 72.1
+FP32_PACKED_VALU_PEAK_MEASURED_TFLOPS = 141.4
 
 
 def nf(l):

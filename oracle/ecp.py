@@ -1,0 +1,98 @@
+"""Brute-force CPU oracle of the scalar ECP integrals (NumPy).  TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+
+What is computed (definition, as in the reference's path ``get_ecp`` -> ``ECPscalar``, /root/reference/jqc/backend/ecp.py:1371-1503;
+the kernels ``ecp/ecp_type1.cu`` / ``ecp_type2.cu`` evaluate it semi-analytically): for every atom C that carries a potential
+
+    V_ab = <a| U_L(r_C) |b>  +  sum_l <a| U_l(r_C) sum_m |l m><l m| |b>,        U(r) = sum_k c_k r^(n_k - 2) exp(-zeta_k r^2)
+
+with the local channel U_L (``ANG_OF = -1``) acting on everything and the semi-local channels through the projectors onto the
+spherical harmonics around C.  The reference's own tests compare against libcint's ``mol.intor("ECPscalar")``
+(``jqc/pyscf/tests/test_ecp_small.py:118-131``); libcint and PySCF are third party and absent from this image, and the tests
+hold no stored numbers, so NO reference-held value pins this row: the oracle is the definition evaluated by plain quadrature,
+checked against closed forms where they exist (tests/test_ecp_oracle.py).
+
+Method (deliberately different from the device kernels: no Bessel functions, no angular tables, no binomial expansions):
+a product grid around C -- Gauss-Legendre panels in r, Gauss-Legendre in cos(theta), uniform in phi -- on which the AOs are
+evaluated directly (oracle/dft.py).  Local channel: sum_g w_g U_L(r_g) phi_a phi_b.  Semi-local: per radius the projections
+A_a,lm(r) = sum_Omega w_Omega Y_lm(Omega) phi_a(C + r Omega), then sum_r w_r r^2 U_l(r) A_a,lm A_b,lm.  The angular order is
+raised until the result is stable (``ecp_scalar(..., nang=...)``); the cost is O(nao x points), fine for the test molecules.
+"""
+import numpy as np
+
+from . import dft
+
+
+def _radial(nodes_per_panel=48, edges=(0.0, 0.05, 0.2, 0.5, 1.0, 2.0, 3.5, 6.0, 10.0, 16.0)):
+    x, w = np.polynomial.legendre.leggauss(nodes_per_panel)
+    rs, ws = [], []
+    for a, b in zip(edges[:-1], edges[1:]):
+        rs.append(0.5 * (b - a) * x + 0.5 * (a + b))
+        ws.append(0.5 * (b - a) * w)
+    return np.concatenate(rs), np.concatenate(ws)
+
+
+def _angular(ntheta):
+    ct, wt = np.polynomial.legendre.leggauss(ntheta)
+    nphi = 2 * ntheta
+    phi = (np.arange(nphi) + 0.5) * 2 * np.pi / nphi
+    st = np.sqrt(1 - ct * ct)
+    xyz = np.stack([np.outer(st, np.cos(phi)).ravel(), np.outer(st, np.sin(phi)).ravel(), np.repeat(ct, nphi)], 1)
+    return xyz, np.repeat(wt, nphi) * (2 * np.pi / nphi)
+
+
+def real_sph_harm(l, xyz):
+    """Orthonormal real spherical harmonics of degree l on unit vectors xyz [n, 3]: [2l+1, n] (any orthonormal basis of the
+    degree-l subspace gives the same projector; this one comes from scipy's complex Y_l^m)."""
+    import scipy.special as sp
+    theta = np.arccos(np.clip(xyz[:, 2], -1, 1))
+    phi = np.arctan2(xyz[:, 1], xyz[:, 0])
+    # (scipy >= 1.15: sph_harm_y(l, m, polar, azimuth); older: sph_harm(m, l, azimuth, polar))
+    ycomplex = (lambda m: sp.sph_harm_y(l, m, theta, phi)) if hasattr(sp, "sph_harm_y") else (lambda m: sp.sph_harm(m, l, phi, theta))
+    out = [np.real(ycomplex(0))]
+    for m in range(1, l + 1):
+        y = ycomplex(m)
+        out.append(np.sqrt(2.0) * np.real(y))
+        out.append(np.sqrt(2.0) * np.imag(y))
+    return np.asarray(out)
+
+
+def _u(r, terms):
+    """U(r) of one channel: terms = [(power, zeta[], coef[]), ...]."""
+    v = np.zeros_like(r)
+    for power, zeta, coef in terms:
+        for z, c in zip(zeta, coef):
+            v += c * r ** (power - 2) * np.exp(-z * r * r)
+    return v
+
+
+def ecp_scalar(layout, channels, coords_of_atom, nang=64, nrad=48):
+    """ECP matrix in the INTERNAL Cartesian AO order of ``layout`` (joltqc_amd.pyscf.basis.BasisLayout): [nao_int, nao_int].
+    ``channels`` = joltqc_amd.gto.ecp.channels(mol); ``coords_of_atom[ia]`` = centre of atom ia (Bohr)."""
+    nao = int(layout.ao_loc[-1])
+    V = np.zeros((nao, nao))
+    r, wr = _radial(nrad)
+    ang, wang = _angular(nang)
+    for ia, rows in channels.items():
+        C = np.asarray(coords_of_atom[ia], dtype=float)
+        by_l = {}
+        for l, power, zeta, coef in rows:
+            by_l.setdefault(l, []).append((power, zeta, coef))
+        ylm = {l: real_sph_harm(l, ang) for l in by_l if l >= 0}
+        ul = {l: _u(r, t) for l, t in by_l.items()}
+        for n in range(len(r)):
+            pts = C + r[n] * ang
+            ao = dft.eval_ao_cart(layout.packed, layout.ao_loc, pts)[0]        # [nao, nang_pts]
+            if -1 in by_l:
+                V += (wr[n] * r[n] ** 2 * ul[-1][n]) * (ao * wang) @ ao.T
+            for l, y in ylm.items():
+                A = (ao * wang) @ y.T                                           # [nao, 2l+1]
+                V += (wr[n] * r[n] ** 2 * ul[l][n]) * A @ A.T
+    return V
+
+
+def ecp_scalar_mol(layout, mol, nang=64, nrad=48):
+    """The same matrix in the molecule's own AO basis (spherical or Cartesian), as ``mol.intor("ECPscalar")`` lays it out."""
+    from joltqc_amd.gto import ecp as gecp
+    V = ecp_scalar(layout, gecp.channels(mol), mol.atom_coords(), nang, nrad)
+    T = layout.transform_matrix()
+    return T.T @ V @ T

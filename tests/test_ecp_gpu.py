@@ -1,0 +1,79 @@
+"""Device ECP integrals against the brute-force oracle, through the C ABI (jqc_ecp_scalar).
+
+Molecules, basis and potentials are the reference's own (jqc/pyscf/tests/test_ecp_small.py:28-93: Na2, s/p/d + one g function with
+general contractions; type 1 = local channel only, type 2 = S, P and G projectors), spherical and Cartesian like its
+``test_ecp_type{1,2}_{sph,cart}``.  The reference's bar is |h_gpu - h_libcint| < 1e-6 in the Frobenius norm; libcint is absent
+here, so the comparison is with oracle/ecp.py (PARITY UNPINNED), at 1e-8 of the largest element."""
+import numpy as np
+import pytest
+
+from test_ecp_oracle import ECP_TYPE1, ECP_TYPE2, na2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cart", [False, True])
+@pytest.mark.parametrize("kind", ["type1", "type2"])
+def test_get_ecp_against_the_oracle(kind, cart):
+    from joltqc_amd.backend import ecp as becp
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import ecp as oecp
+    mol = na2(ECP_TYPE1 if kind == "type1" else ECP_TYPE2, cart=cart)
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    ref = oecp.ecp_scalar_mol(lay, mol, nang=32, nrad=32)
+    got = becp.get_ecp(mol).cpu().numpy()
+    assert got.shape == (mol.nao, mol.nao)
+    scale = np.abs(ref).max()
+    assert np.abs(got - got.T).max() < 1e-12 * scale
+    assert np.abs(got - ref).max() < 1e-8 * scale, np.abs(got - ref).max() / scale
+    assert np.linalg.norm(got - ref) < 1e-6                       # the reference's own criterion (Frobenius norm)
+    # the radial grid is converged: 128 and 192 points give the same matrix
+    for nr in (128, 192):
+        other = becp.get_ecp(mol, nr=nr).cpu().numpy()
+        assert np.abs(other - got).max() < 1e-10 * scale, (nr, np.abs(other - got).max() / scale)
+
+
+def test_both_channel_types_far_and_near_the_centre():
+    """Local + semi-local channels on ONE atom of a heteronuclear pair with tight and diffuse shells, a 1/r and a 1/r^2 term:
+    shells on the ECP centre (kappa = 0 branch of the Bessel functions), on the neighbour 1.1 and 3 Bohr away (series and
+    upward-recurrence branches: kappa = 2 alpha r |A - C| passes 16)."""
+    from joltqc_amd.backend import ecp as becp
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import ecp as oecp
+    bas = {"Na": [[0, [35.0, 0.3], [4.0, 0.5], [0.6, 0.4]], [1, [2.2, 1.0]], [2, [0.9, 1.0]], [3, [1.1, 1.0]]],
+           "H": [[0, [6.0, 0.4], [0.9, 0.7]], [1, [1.4, 1.0]], [2, [1.0, 1.0]], [4, [1.3, 1.0]]]}
+    text = "Na nelec 10\nNa ul\n1 2.1 -1.5\n2 0.9 0.7\n0 3.0 0.4\nNa S\n2 5.0 40.0\n0 1.2 2.0\nNa P\n2 3.1 12.0\nNa D\n1 1.7 -3.0\nNa F\n2 1.1 1.5\n"
+    for dist in (1.1, 3.0):
+        mol = mole.Mole(atom=f"Na 0.1 -0.2 0.3; H {0.1 + dist * 0.6} {-0.2 + dist * 0.0} {0.3 + dist * 0.8}", basis=bas,
+                        ecp={"Na": text}, unit="B")
+        lay = BasisLayout.from_mol(mol, alignment=1)
+        ref = oecp.ecp_scalar_mol(lay, mol, nang=64, nrad=48)
+        got = becp.get_ecp(lay).cpu().numpy()
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() < 1e-8 * scale, (dist, np.abs(got - ref).max() / scale)
+        # block by block (the potential is short-ranged: at 3 Bohr the H-H block is 1e-4 of the largest element; the oracle's own
+        # angular quadrature is converged to 2e-9 of that block there, 1e-14 elsewhere)
+        n1 = 1 + 3 + 5 + 7
+        for name, sl in (("NaNa", (slice(0, n1), slice(0, n1))), ("NaH", (slice(0, n1), slice(n1, None))), ("HH", (slice(n1, None), slice(n1, None)))):
+            blk = np.abs(ref[sl]).max()
+            assert np.abs(got[sl] - ref[sl]).max() < 1e-7 * blk, (dist, name, np.abs(got[sl] - ref[sl]).max() / blk)
+
+
+def test_patch_interface_mirrors_the_reference():
+    """jqc/pyscf/ecp.py:27-118: apply_ecp -> dict of closures, patch_ecp_integrals installs mol.get_ecp, restore removes it; a
+    molecule without ECP is left alone."""
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import ecp as pecp
+    mol = na2(ECP_TYPE1)
+    patches = pecp.apply_ecp(mol)
+    assert set(patches) == {"get_ecp", "ecp_kernel", "precision", "original_methods"} and patches["precision"] == "fp64"
+    with pytest.raises(ValueError):
+        pecp.apply_ecp(mol, precision="fp32")
+    pecp.patch_ecp_integrals(mol)
+    h = mol.get_ecp().cpu().numpy()
+    assert h.shape == (mol.nao, mol.nao) and np.abs(h).max() > 0.1 and mol._jqc_ecp_info["precision"] == "fp64"
+    pecp.restore_ecp_methods(mol)
+    assert not hasattr(mol, "_jqc_ecp_info") and "get_ecp" not in mol.__dict__
+    plain = mole.Mole(atom="H 0 0 0; H 0 0 1.4", basis="def2-svp", unit="B")
+    assert pecp.apply_ecp(plain) == {}

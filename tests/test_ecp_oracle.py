@@ -1,0 +1,112 @@
+"""CPU checks of the ECP row: the input layer, the host-side tables of the device kernel and the
+brute-force oracle (oracle/ecp.py) against closed forms.  PARITY UNPINNED: the reference's own tests compare with libcint's
+``ECPscalar`` (jqc/pyscf/tests/test_ecp_small.py:118-131), which is third party and absent here, and store no numbers.
+The molecules are the reference's: two Na atoms with its inline basis (s with three general contractions, p with two, d, and a
+g function) and its type-1 (local channel) / type-2 (S, P and G projectors) potentials (test_ecp_small.py:28-93)."""
+import math
+
+import numpy as np
+import pytest
+
+BAS = [[4, [1.8, 1.0]],
+       [0, [2.8, 0.021087, -0.00454, 0.0], [1.319, 0.346129, -0.170352, 0.0], [0.9059, 0.039378, 0.140382, 1.0]],
+       [1, [2.133, 0.086866, 0.0], [1.2, 0.0, 0.5], [0.3827, 0.501008, 1.0]],
+       [2, [0.3827, 1.0]]]
+ECP_TYPE1 = "Na nelec 10\nNa ul\n2       1.0                   0.5\n"
+ECP_TYPE2 = """Na nelec 10
+Na S
+2      13.652203             732.2692
+2       6.826101              26.484721
+Na P
+2      10.279868             299.489474
+2       5.139934              26.466234
+Na G
+2       7.349859             124.457595
+2       3.674929              14.035995
+"""
+ATOM = "Na 0.5 0.5 0.; Na 0. 1. 1."
+
+
+def na2(ecp_text, cart=False):
+    from joltqc_amd.gto import mole
+    return mole.Mole(atom=ATOM, basis={"Na": BAS}, ecp={"Na": ecp_text}, cart=cart)
+
+
+def test_parse_ecp_builds_pyscf_rows():
+    from joltqc_amd.gto import ecp as gecp
+    mol = na2(ECP_TYPE2)
+    assert mol._ecpbas.shape == (6, 8)                       # two atoms x three channels, one radial power each
+    assert sorted(set(mol._ecpbas[:, gecp.ANG_OF].tolist())) == [0, 1, 4]
+    assert (mol._ecpbas[:, gecp.NPRIM_OF] == 2).all() and (mol._ecpbas[:, gecp.RADI_POWER] == 2).all()
+    assert mol.atom_charges().tolist() == [1, 1] and mol.nelectron == 2          # 10 core electrons per atom removed
+    ch = gecp.channels(mol)
+    l, power, zeta, coef = ch[0][0]
+    assert (l, power) == (0, 2) and np.allclose(zeta, [13.652203, 6.826101]) and np.allclose(coef, [732.2692, 26.484721])
+    m1 = na2(ECP_TYPE1)
+    assert m1._ecpbas[:, gecp.ANG_OF].tolist() == [-1, -1]
+
+
+def test_real_spherical_harmonic_table_is_orthonormal():
+    """ylm_table (device input): int Y_lm Y_l'm' dOmega = delta, from the exact monomial integrals over the sphere."""
+    from joltqc_amd.backend import ecp as becp
+    from joltqc_amd.gto.c2s import cart_powers
+    tab = becp.ylm_table(4)
+
+    def dfact(n):
+        return 1.0 if n <= 0 else float(np.prod(np.arange(n, 0, -2)))
+
+    def mono(a, b, c):
+        if a % 2 or b % 2 or c % 2:
+            return 0.0
+        return 4 * math.pi * dfact(a - 1) * dfact(b - 1) * dfact(c - 1) / dfact(a + b + c + 1)
+    for l1 in range(5):
+        for l2 in range(l1, 5):
+            p1, p2 = cart_powers(l1), cart_powers(l2)
+            S = np.array([[mono(a[0] + b[0], a[1] + b[1], a[2] + b[2]) for b in p2] for a in p1])
+            G = tab[l1 * l1:(l1 + 1) ** 2, :len(p1)] @ S @ tab[l2 * l2:(l2 + 1) ** 2, :len(p2)].T
+            assert np.abs(G - (np.eye(2 * l1 + 1) if l1 == l2 else 0.0)).max() < 1e-13, (l1, l2)
+
+
+def test_radial_grid_integrates_gaussians():
+    from joltqc_amd.backend import ecp as becp
+    r, w = becp.radial_grid()
+    for a, n in ((0.1, 2), (1.0, 2), (30.0, 4), (2000.0, 2), (0.3, 8), (5e4, 2), (13.6, 0), (13.6, 1), (800.0, 0), (5e4, 0)):
+        exact = math.gamma((n + 1) / 2) / (2 * a ** ((n + 1) / 2))
+        assert abs((w * r ** n * np.exp(-a * r * r)).sum() / exact - 1) < 1e-13, (a, n)
+
+
+def test_oracle_against_closed_forms_on_the_ecp_centre():
+    """One atom, everything centred on the ECP atom: <s|U_0 P_0|s> = <s|U_0|s> = sum c c' int r^2 R R' U dr (P_0 s = s), and a
+    projector of another l annihilates an s function; the local channel on an s pair is the same radial integral."""
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import ecp as oecp
+    bas = {"Na": [[0, [1.3, 1.0]], [0, [0.4, 1.0]], [1, [0.9, 1.0]]]}
+    for chan in ("S", "ul", "P"):
+        mol = mole.Mole(atom="Na 0 0 0", basis=bas, ecp={"Na": f"Na nelec 10\nNa {chan}\n2 1.1 3.0\n1 0.7 -0.8\n"})
+        lay = BasisLayout.from_mol(mol, alignment=1)
+        V = oecp.ecp_scalar_mol(lay, mol, nang=24, nrad=32)
+        gi = lambda n, a: math.gamma((n + 1) / 2) / (2 * a ** ((n + 1) / 2))
+        norm = lambda a: 1 / math.sqrt(gi(2, 2 * a))               # radial normalisation of an s primitive
+        ex = lambda a, b: norm(a) * norm(b) * (3.0 * gi(2, a + b + 1.1) - 0.8 * gi(1, a + b + 0.7))
+        want = np.array([[ex(1.3, 1.3), ex(1.3, 0.4)], [ex(0.4, 1.3), ex(0.4, 0.4)]])
+        got = V[:2, :2]
+        if chan == "P":
+            assert np.abs(got).max() < 1e-13                      # a p projector sees no s function
+            px = 3.0 * gi(4, 1.8 + 1.1) - 0.8 * gi(3, 1.8 + 0.7)
+            assert abs(V[2, 2] - px / gi(4, 1.8)) < 1e-12
+        else:
+            assert np.abs(got - want).max() < 1e-12, (chan, got, want)
+            assert np.abs(V[:2, 2:]).max() < 1e-13
+
+
+@pytest.mark.parametrize("text", [ECP_TYPE1, ECP_TYPE2])
+def test_oracle_is_converged_and_symmetric_on_the_reference_molecules(text):
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import ecp as oecp
+    mol = na2(text)
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    a = oecp.ecp_scalar_mol(lay, mol, nang=32, nrad=32)
+    b = oecp.ecp_scalar_mol(lay, mol, nang=40, nrad=40)
+    assert a.shape == (mol.nao, mol.nao) and np.abs(a - a.T).max() < 1e-12 * np.abs(a).max()
+    assert np.abs(a - b).max() < 1e-12 * np.abs(b).max()

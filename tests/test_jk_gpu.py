@@ -225,6 +225,7 @@ def test_ket_chunks_and_workgroup_splits(monkeypatch):
 
 ORED, PAROOT, NDM2 = 1 << 18, 1 << 19, 1 << 20        # include/jqc_hip.h (round 3: owner reduction, per-root phase A, two DMs)
 RSPLIT = lambda code: code << 22                      # (round 4: Rys roots in code + 1 groups through phase A / phase B)
+QUAD = 1 << 24                                        # (round 5: one quartet per quad of lanes; classes with a p shell, <= 4 roots)
 
 
 @pytest.mark.parametrize("variant", [0x21, 0x21 | 0x100, 0x21 | 0x400, 0x21 | 0x100 | 0x400, 0x22, 0x32, 0x21 | 0x800,
@@ -232,11 +233,12 @@ RSPLIT = lambda code: code << 22                      # (round 4: Rys roots in c
                                      0x921 | ORED, 0x921 | ORED | PAROOT, 0xd21 | ORED | PAROOT, 0x521 | ORED, 0x421 | ORED | PAROOT,
                                      0x30521 | ORED, 0x21 | ORED, 0x10d21 | ORED | PAROOT,
                                      0xd21 | ORED | RSPLIT(1), 0xd21 | ORED | RSPLIT(2), 0x521 | ORED | RSPLIT(1), 0x121 | ORED | RSPLIT(1),
-                                     0xd21 | ORED | PAROOT | RSPLIT(1)])
+                                     0xd21 | ORED | PAROOT | RSPLIT(1),
+                                     0x1022 | QUAD, 0x1122 | QUAD, 0x0132 | QUAD, 0x1032 | QUAD])
 def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
     """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
     L2 | single TRR buffer | wave-local steps | j in registers | 2, 4, 8 ket pairs per iteration | owner reduction | per-root
-    phase A | integral-chunk caps | root groups; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.
+    phase A | integral-chunk caps | root groups | one quartet per quad of lanes; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.
     Role of the reference's 1q1t == 1qnt cross-check (jqc/backend/data/generate_fragment.py:278-309)."""
     from joltqc_amd.backend import jk as router
     from oracle import dense
@@ -324,6 +326,9 @@ def test_two_ranks_share_the_quartets_and_allreduce_the_fock_matrix():
     assert min(res[0][3], res[1][3]) > 0.25 * n_all
 
 
+_CLASS_ORACLE = {}
+
+
 @pytest.mark.parametrize("mode", ["jk", "j", "k", "lr", "fp32", "k_lr", "fp32_lr", "jk_main", "k_lr_main", "jk_2dm", "jk_2dm_main",
                                   "jk_3dm", "fused", "fused_main", "fused32", "fused_lr"])
 def test_every_angular_class_against_the_oracle(mode, monkeypatch):
@@ -378,7 +383,12 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
                             continue
                         nclass += 1
                         key = "%d%d%d%d" % (li, lj, lk, ll)
-                        rj, rk = dense.get_jk(lay, dm, hermi=1, quartets=allq[sel], omega=omega, with_j=with_j, with_k=with_k)
+                        # (the oracle's J and K of a class are evaluated once per (density, omega) and shared by the modes that
+                        #  differ only in what the DEVICE does with them: 16 modes, 4 oracle passes -- the suite's time budget)
+                        ck = (key, omega, dm.shape)
+                        if ck not in _CLASS_ORACLE:
+                            _CLASS_ORACLE[ck] = dense.get_jk(lay, dm, hermi=1, quartets=allq[sel], omega=omega)
+                        rj, rk = _CLASS_ORACLE[ck]
                         os.environ["JQC_ONLY_CLASS"] = key
                         get_jk = jkmod.generate_jk_kernel(lay, cutoff_fp64=cut64, cutoff_fp32=1e-13)
                         vj, vk = get_jk(mol, dm, hermi=1, with_j=with_j, with_k=with_k, omega=omega)

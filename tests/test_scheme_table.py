@@ -167,3 +167,6 @@ def test_increment_policy_schedules_full_rebuilds():
     assert p.full_build(0.0)
     p.reset()
     assert p.full_build(5.0) and not p.full_build(4.0)
+    # a restart on the same closures (second kernel(), new dm0): the increment GROWS against the reference of a converged run
+    p.reset()
+    assert [p.full_build(d) for d in (1.0, 1e-2, 1e-4, 2e-7, 1.5e-7, 0.8, 0.3)] == [True, False, True, False, False, True, False]
