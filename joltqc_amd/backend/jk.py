@@ -47,6 +47,7 @@ def class_cost_table():
 
 
 TILE1Q_MAX_NINT = int(os.environ.get("JQC_TILE1Q_MAX", "108"))   # above this the lane-per-quartet body spills heavily
+QUAD_FORCE_MAX = int(os.environ.get("JQC_QUAD_MAX", "270"))      # largest integral block the quad form (JQC_VARIANT_QUAD) is tried on: 90 integrals per lane
 TILE1Q_FORCE_MAX = 200    # largest integral block the lane-per-quartet mode is ever tried on (512 VGPRs at 1 wave/SIMD)
 
 
@@ -116,7 +117,8 @@ def supports_ndm2(ang, v):
 def forced_variant(ang, v):
     """Variant code ``v`` adjusted to what class ``ang`` supports: lane-per-quartet only where the integral block fits,
     the wave-local variant only where a quartet fits one wave."""
-    if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > TILE1Q_FORCE_MAX:
+    # (the quad form holds a third of the block per lane: up to 3 x 90 integrals)
+    if (v & 0xf) == _lib.ALGO_TILE1Q and nint(ang) > (QUAD_FORCE_MAX if (v & VARIANT_QUAD) and 1 in ang else TILE1Q_FORCE_MAX):
         return _lib.ALGO_TILE
     if (v & 0xf) == _lib.ALGO_TILE1Q:
         v &= ~(0x30000 | VARIANT_ORED | VARIANT_PAROOT | VARIANT_RSPLIT(3))   # integral chunks, owner reduction, per-root phase A,

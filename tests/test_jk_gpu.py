@@ -408,7 +408,8 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
         os.environ.pop("JQC_ONLY_CLASS", None)
     assert nclass == (140 if lmax == 4 else 65) and not bad, bad
     if fused:                   # the packed-FP32 phase did run in the lane-per-quartet classes (46 of the 140 in the main table)
-        assert nfused >= 25 and (mode != "fused" or nboth >= 10), (nfused, nboth)        # (measured: 29-30 classes; both phases in 12)
+        # (measured: 21 classes, both phases in 9; before nine classes moved to the quad form, which has no fused build: 29-30 and 12)
+        assert nfused >= 18 and (mode != "fused" or nboth >= 7), (nfused, nboth)
 
 
 @pytest.mark.parametrize("cart", [False, True])

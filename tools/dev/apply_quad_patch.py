@@ -32,6 +32,18 @@ static_assert(XS >= 0, "QUAD: the class needs a p shell");
 static_assert(TILE_1Q && !MIXED && NROOTS <= 4, "QUAD: lane-per-quartet builds up to four Rys roots");
 constexpr int NXI = XS == 0 ? 1 : NFI, NXJ = XS == 1 ? 1 : NFJ, NXK = XS == 2 ? 1 : NFK, NXL = XS == 3 ? 1 : NFL;
 constexpr int NINTQ = NXI * NXJ * NXK * NXL;              // integrals per lane
+// chunks of the lane's block over the components of a second index (QY = 0..3 = i, j, k, l; -1: none): QNCH passes, each with its own
+// evaluation of the recurrences and roots, for the classes whose third of the block would not fit the registers
+#ifndef QNCH
+#define QNCH 1
+#endif
+#ifndef QY
+#define QY (-1)
+#endif
+static_assert(QNCH == 1 || (QY >= 0 && QY <= 3 && QY != XS), "QUAD chunks: over an index other than the split one");
+constexpr int CI = QY == 0 ? NXI / QNCH : NXI, CJ = QY == 1 ? NXJ / QNCH : NXJ, CK = QY == 2 ? NXK / QNCH : NXK, CL = QY == 3 ? NXL / QNCH : NXL;
+static_assert(CI * CJ * CK * CL * QNCH == NINTQ, "QUAD chunks must divide the component count of their index");
+constexpr int NINTC = CI * CJ * CK * CL;                  // integrals per lane and chunk
 constexpr int GS_X = XS == 0 ? GS_I : XS == 1 ? GS_J : XS == 2 ? GS_K : GS_L;
 // component n of a shell of angular momentum l, read with the axes rotated by c (own axis first): exponents (p, q, r) on
 // (a0, a1, a2) = (c, c+1, c+2) mod 3  ->  index of the Cartesian component with those exponents on (x, y, z)
