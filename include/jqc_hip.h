@@ -58,6 +58,9 @@ extern "C" {
                                      * lane c of the quad owns Cartesian axis c (its recurrences, a third of the integral block), the
                                      * 1-D arrays of the neighbouring axes arrive by quad-permute DPP moves, each lane evaluates one Rys
                                      * root; 64 quartets per pass, <= 256 registers (no AGPR copies) for the 100-180-integral classes */
+#define JQC_VARIANT_QCHUNK(code, index) (((code) << 25) | ((index) << 27)) /* quad builds of the 270-330-integral classes: the lane's third of
+                                     * the integral block is evaluated in 2 / 3 / 5 chunks (code 1 / 2 / 3) over the Cartesian components of
+                                     * shell `index` (0..3 = i, j, k, l; not the split p shell), recurrences and roots redone per chunk */
 #define JQC_VARIANT_MIXED (1 << 21) /* FP64 lane-per-quartet build with BOTH precision windows in one launch: quartets with an
                                       estimate above cut_hi in FP64, those in (cut_lo, cut_hi] in FP32, two per lane as packed
                                       2-vectors (v_pk_fma_f32); one staging / screening / flush per tile pair (replaces the reference's

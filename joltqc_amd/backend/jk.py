@@ -47,7 +47,7 @@ def class_cost_table():
 
 
 TILE1Q_MAX_NINT = int(os.environ.get("JQC_TILE1Q_MAX", "108"))   # above this the lane-per-quartet body spills heavily
-QUAD_FORCE_MAX = int(os.environ.get("JQC_QUAD_MAX", "270"))      # largest integral block the quad form (JQC_VARIANT_QUAD) is tried on: 90 integrals per lane
+QUAD_FORCE_MAX = int(os.environ.get("JQC_QUAD_MAX", "330"))      # largest integral block the quad form (JQC_VARIANT_QUAD) is tried on (with chunks)
 TILE1Q_FORCE_MAX = 200    # largest integral block the lane-per-quartet mode is ever tried on (512 VGPRs at 1 wave/SIMD)
 
 
@@ -66,6 +66,8 @@ def class_key(ang):
 VARIANT_ORED, VARIANT_PAROOT, VARIANT_NDM2 = 1 << 18, 1 << 19, 1 << 20     # include/jqc_hip.h
 VARIANT_RSPLIT = lambda code: code << 22      # row-lane mode: Rys roots in code + 1 groups through phase A / B (half the TRR array)
 VARIANT_QUAD = 1 << 24         # lane-per-quartet mode with one quartet per DPP quad of lanes (classes with a p shell, <= 4 Rys roots)
+VARIANT_QCHUNK = lambda code, index: (code << 25) | (index << 27)     # quad builds: 2 / 3 / 5 chunks (code 1 / 2 / 3) over the components of shell `index`
+QCHUNKS = (1, 2, 3, 5)
 VARIANT_MIXED = 1 << 21        # both precision windows in one launch of an FP64 lane-per-quartet build (FP32 phase packed)
 
 
@@ -123,10 +125,17 @@ def forced_variant(ang, v):
     if (v & 0xf) == _lib.ALGO_TILE1Q:
         v &= ~(0x30000 | VARIANT_ORED | VARIANT_PAROOT | VARIANT_RSPLIT(3))   # integral chunks, owner reduction, per-root phase A,
                                                                               # root groups: row-lane mode only
+    nf = lambda l: (l + 1) * (l + 2) // 2
     if (v & VARIANT_QUAD) and ((v & 0xf) != _lib.ALGO_TILE1Q or 1 not in ang or sum(ang) // 2 + 1 > 4):
         v &= ~VARIANT_QUAD                            # quad form: lane-per-quartet builds of classes with a p shell, <= 4 roots
     if v & VARIANT_QUAD:
         v &= ~0xc000                                  # (strided queue / row-ordered contraction belong to the one-lane form)
+        code, qy = (v >> 25) & 3, (v >> 27) & 3
+        xs = 3 if ang[3] == 1 else 2 if ang[2] == 1 else 1 if ang[1] == 1 else 0          # the split p shell (jk_tile.hip XS)
+        if code and (qy == xs or nf(ang[qy]) % QCHUNKS[code]):
+            v &= ~(0xf << 25)                         # chunks must divide the component count of another shell
+    else:
+        v &= ~(0xf << 25)
     if (v & 0xf) != _lib.ALGO_TILE1Q:
         v &= ~(0xf000 | VARIANT_MIXED)                # several ket pairs per iteration, strided queue, row-ordered contraction,
                                                       # fused precision phases: lane-per-quartet mode only

@@ -607,7 +607,8 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     const int v_ecap = (algo_variant >> 16) & 3;
     const int v_ored = (algo_variant >> 18) & 1, v_paroot = (algo_variant >> 19) & 1, v_ndm2 = (algo_variant >> 20) & 1;
     const int v_mixed = (algo_variant >> 21) & 1, v_rsplit = (algo_variant >> 22) & 3;
-    const int v_quad = (algo_variant >> 24) & 1;
+    const int v_quad = (algo_variant >> 24) & 1, v_qnch = (algo_variant >> 25) & 3, v_qy = (algo_variant >> 27) & 3;
+    if (v_qnch && !v_quad) return fail(-1, "JQC_VARIANT_QCHUNK: quad builds only");
     if (v_quad && (algo != JQC_ALGO_TILE1Q || v_mixed || (li + lj + lk + ll) / 2 + 1 > 4 || (li != 1 && lj != 1 && lk != 1 && ll != 1)))
         return fail(-1, "JQC_VARIANT_QUAD: lane-per-quartet builds of classes with a p shell and at most four Rys roots");
     if (v_mixed && (algo != JQC_ALGO_TILE1Q || fp32 || v_ndm2))
@@ -653,6 +654,11 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
         if (v_mixed) d.push_back("-DMIXED=1");
         if (v_rsplit) d.push_back("-DRSPLIT=" + std::to_string(v_rsplit + 1));
         if (v_quad) d.push_back("-DQUAD=1");
+        if (v_qnch) {
+            static const int nch[4] = {1, 2, 3, 5};
+            d.push_back("-DQNCH=" + std::to_string(nch[v_qnch]));
+            d.push_back("-DQY=" + std::to_string(v_qy));
+        }
         if (tiled) {
             // Builds that spill vector registers to scratch also re-read the staging pointers from the kernarg segment
             // (KARG_RELOAD in jk_tile.hip: ~45 fewer SGPRs spilled to VGPR lanes); builds without scratch keep the

@@ -373,6 +373,19 @@ static_assert(XS >= 0, "QUAD: the class needs a p shell");
 static_assert(TILE_1Q && !MIXED && NROOTS <= 4, "QUAD: lane-per-quartet builds up to four Rys roots");
 constexpr int NXI = XS == 0 ? 1 : NFI, NXJ = XS == 1 ? 1 : NFJ, NXK = XS == 2 ? 1 : NFK, NXL = XS == 3 ? 1 : NFL;
 constexpr int NINTQ = NXI * NXJ * NXK * NXL;              // integrals per lane
+// chunks of the lane's block over the components of a second index (QY = 0..3 = i, j, k, l; -1: none): QNCH passes, each with its own
+// evaluation of the recurrences and roots, for the classes whose third of the block would not fit the registers
+#ifndef QNCH
+#define QNCH 1
+#endif
+#ifndef QY
+#define QY (-1)
+#endif
+
+static_assert(QNCH == 1 || (QY >= 0 && QY <= 3 && QY != XS), "QUAD chunks: over an index other than the split one");
+constexpr int CI = QY == 0 ? NXI / QNCH : NXI, CJ = QY == 1 ? NXJ / QNCH : NXJ, CK = QY == 2 ? NXK / QNCH : NXK, CL = QY == 3 ? NXL / QNCH : NXL;
+static_assert(CI * CJ * CK * CL * QNCH == NINTQ, "QUAD chunks must divide the component count of their index");
+constexpr int NINTC = CI * CJ * CK * CL;                  // integrals per lane and chunk
 constexpr int GS_X = XS == 0 ? GS_I : XS == 1 ? GS_J : XS == 2 ? GS_K : GS_L;
 // component n of a shell of angular momentum l, read with the axes rotated by c (own axis first): exponents (p, q, r) on
 // (a0, a1, a2) = (c, c+1, c+2) mod 3  ->  index of the Cartesian component with those exponents on (x, y, z)
@@ -1055,9 +1068,14 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 if (ish == jsh) fac *= real(0.5);
                 if (ksh == lsh) fac *= real(0.5);
                 if (ish == ksh && jsh == lsh) fac *= real(0.5);
-                real I[NINTQ];
+                // the lane's third of the block is evaluated in QNCH chunks over the components of index QY (recurrences and roots
+                // redone per chunk: the price of keeping <= ~60 integrals per lane for the 270-540-integral classes)
 #pragma unroll
-                for (int n = 0; n < NINTQ; n++) I[n] = 0;
+                for (int ch = 0; ch < QNCH; ch++) {
+                const int i0 = QY == 0 ? ch * CI : 0, j0 = QY == 1 ? ch * CJ : 0, k0 = QY == 2 ? ch * CK : 0, l0 = QY == 3 ? ch * CL : 0;
+                real I[NINTC];
+#pragma unroll
+                for (int n = 0; n < NINTC; n++) I[n] = 0;
                 for (int kp = 0; kp < npk; kp++)
                 for (int lp = 0; lp < npl; lp++) {
                     const real ckcl = pk[(kp * 3 + lp) * 3], inv_akl = pk[(kp * 3 + lp) * 3 + 1], akl = pk[(kp * 3 + lp) * 3 + 2];
@@ -1094,31 +1112,31 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             for (int e = 0; e < GSIZE; e++)
                                 if ((e / GS_X) % 2 == 0) { g1[e] = dpp_quad<DPP_ROT1>(g0[e]); g2[e] = dpp_quad<DPP_ROT2>(g0[e]); }
 #pragma unroll
-                            for (int i = 0; i < NXI; i++)
+                            for (int i = 0; i < CI; i++)
 #pragma unroll
-                            for (int j = 0; j < NXJ; j++)
+                            for (int j = 0; j < CJ; j++)
 #pragma unroll
-                            for (int k = 0; k < NXK; k++)
+                            for (int k = 0; k < CK; k++)
 #pragma unroll
-                            for (int l = 0; l < NXL; l++) {
-                                const int e0 = TI.x[i] * GS_I + TJ.x[j] * GS_J + TK.x[k] * GS_K + TL.x[l];
-                                const int e1 = TI.y[i] * GS_I + TJ.y[j] * GS_J + TK.y[k] * GS_K + TL.y[l];
-                                const int e2 = TI.z[i] * GS_I + TJ.z[j] * GS_J + TK.z[k] * GS_K + TL.z[l];
-                                I[((i * NXJ + j) * NXK + k) * NXL + l] += g0[e0] * g1[e1] * g2[e2];
+                            for (int l = 0; l < CL; l++) {
+                                const int e0 = TI.x[i0 + i] * GS_I + TJ.x[j0 + j] * GS_J + TK.x[k0 + k] * GS_K + TL.x[l0 + l];
+                                const int e1 = TI.y[i0 + i] * GS_I + TJ.y[j0 + j] * GS_J + TK.y[k0 + k] * GS_K + TL.y[l0 + l];
+                                const int e2 = TI.z[i0 + i] * GS_I + TJ.z[j0 + j] * GS_J + TK.z[k0 + k] * GS_K + TL.z[l0 + l];
+                                I[((i * CJ + j) * CK + k) * CL + l] += g0[e0] * g1[e1] * g2[e2];
                             }
                         }
                     }
                 }
                 // ---- AO offsets of the rotated components: index X carries component ax0, the others the rotation table
-                int oi[NXI], oj[NXJ], ok[NXK], ol[NXL];
+                int oi[CI], oj[CJ], ok[CK], ol[CL];
 #pragma unroll
-                for (int n = 0; n < NXI; n++) oi[n] = a * NFI + (XS == 0 ? ax0 : ax0 == 0 ? n : ax0 == 1 ? rot_comp(LI, 1, n) : rot_comp(LI, 2, n));
+                for (int n = 0; n < CI; n++) oi[n] = a * NFI + (XS == 0 ? ax0 : ax0 == 0 ? i0 + n : ax0 == 1 ? rot_comp(LI, 1, i0 + n) : rot_comp(LI, 2, i0 + n));
 #pragma unroll
-                for (int n = 0; n < NXJ; n++) oj[n] = b * NFJ + (XS == 1 ? ax0 : ax0 == 0 ? n : ax0 == 1 ? rot_comp(LJ, 1, n) : rot_comp(LJ, 2, n));
+                for (int n = 0; n < CJ; n++) oj[n] = b * NFJ + (XS == 1 ? ax0 : ax0 == 0 ? j0 + n : ax0 == 1 ? rot_comp(LJ, 1, j0 + n) : rot_comp(LJ, 2, j0 + n));
 #pragma unroll
-                for (int n = 0; n < NXK; n++) ok[n] = c * NFK + (XS == 2 ? ax0 : ax0 == 0 ? n : ax0 == 1 ? rot_comp(LK, 1, n) : rot_comp(LK, 2, n));
+                for (int n = 0; n < CK; n++) ok[n] = c * NFK + (XS == 2 ? ax0 : ax0 == 0 ? k0 + n : ax0 == 1 ? rot_comp(LK, 1, k0 + n) : rot_comp(LK, 2, k0 + n));
 #pragma unroll
-                for (int n = 0; n < NXL; n++) ol[n] = d * NFL + (XS == 3 ? ax0 : ax0 == 0 ? n : ax0 == 1 ? rot_comp(LL, 1, n) : rot_comp(LL, 2, n));
+                for (int n = 0; n < CL; n++) ol[n] = d * NFL + (XS == 3 ? ax0 : ax0 == 0 ? l0 + n : ax0 == 1 ? rot_comp(LL, 1, l0 + n) : rot_comp(LL, 2, l0 + n));
                 if (q_on) {
 #if NDM > 1
 #pragma unroll 1
@@ -1137,76 +1155,77 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 double* qKjl = sKjl + (dmi * NKS + ks) * (WJ * WL);
 #if DO_J
                 {
-                    real jkl[NXK * NXL], dkl[NXK * NXL];
+                    real jkl[CK * CL], dkl[CK * CL];
 #pragma unroll
-                    for (int k = 0; k < NXK; k++)
+                    for (int k = 0; k < CK; k++)
 #pragma unroll
-                        for (int l = 0; l < NXL; l++) { jkl[k * NXL + l] = 0; dkl[k * NXL + l] = qDkl[ol[l] * WK + ok[k]]; }
+                        for (int l = 0; l < CL; l++) { jkl[k * CL + l] = 0; dkl[k * CL + l] = qDkl[ol[l] * WK + ok[k]]; }
 #pragma unroll
-                    for (int i = 0; i < NXI; i++)
+                    for (int i = 0; i < CI; i++)
 #pragma unroll
-                        for (int j = 0; j < NXJ; j++) {
+                        for (int j = 0; j < CJ; j++) {
                             const real dij = qDij[oj[j] * WI + oi[i]];
                             real sj = 0;
 #pragma unroll
-                            for (int n = 0; n < NXK * NXL; n++) {
-                                const real v = I[(i * NXJ + j) * NXK * NXL + n];
+                            for (int n = 0; n < CK * CL; n++) {
+                                const real v = I[(i * CJ + j) * CK * CL + n];
                                 sj += v * dkl[n];
                                 jkl[n] += v * dij;
                             }
                             lds_add(&qJij[oj[j] * WI + oi[i]], (double)sj);
                         }
 #pragma unroll
-                    for (int k = 0; k < NXK; k++)
+                    for (int k = 0; k < CK; k++)
 #pragma unroll
-                        for (int l = 0; l < NXL; l++) lds_add(&qJkl[ol[l] * WK + ok[k]], (double)jkl[k * NXL + l]);
+                        for (int l = 0; l < CL; l++) lds_add(&qJkl[ol[l] * WK + ok[k]], (double)jkl[k * CL + l]);
                 }
 #endif
 #if DO_K
                 {
-                    real kjk[NXJ * NXK], kjl[NXJ * NXL], djk[NXJ * NXK], djl[NXJ * NXL];
+                    real kjk[CJ * CK], kjl[CJ * CL], djk[CJ * CK], djl[CJ * CL];
 #pragma unroll
-                    for (int j = 0; j < NXJ; j++) {
+                    for (int j = 0; j < CJ; j++) {
 #pragma unroll
-                        for (int k = 0; k < NXK; k++) { kjk[j * NXK + k] = 0; djk[j * NXK + k] = qDjk[oj[j] * WK + ok[k]]; }
+                        for (int k = 0; k < CK; k++) { kjk[j * CK + k] = 0; djk[j * CK + k] = qDjk[oj[j] * WK + ok[k]]; }
 #pragma unroll
-                        for (int l = 0; l < NXL; l++) { kjl[j * NXL + l] = 0; djl[j * NXL + l] = qDjl[oj[j] * WL + ol[l]]; }
+                        for (int l = 0; l < CL; l++) { kjl[j * CL + l] = 0; djl[j * CL + l] = qDjl[oj[j] * WL + ol[l]]; }
                     }
 #pragma unroll
-                    for (int i = 0; i < NXI; i++) {
-                        real kik[NXK], kil[NXL], dik[NXK], dil[NXL];
+                    for (int i = 0; i < CI; i++) {
+                        real kik[CK], kil[CL], dik[CK], dil[CL];
 #pragma unroll
-                        for (int k = 0; k < NXK; k++) { kik[k] = 0; dik[k] = qDik[oi[i] * WK + ok[k]]; }
+                        for (int k = 0; k < CK; k++) { kik[k] = 0; dik[k] = qDik[oi[i] * WK + ok[k]]; }
 #pragma unroll
-                        for (int l = 0; l < NXL; l++) { kil[l] = 0; dil[l] = qDil[oi[i] * WL + ol[l]]; }
+                        for (int l = 0; l < CL; l++) { kil[l] = 0; dil[l] = qDil[oi[i] * WL + ol[l]]; }
 #pragma unroll
-                        for (int j = 0; j < NXJ; j++)
+                        for (int j = 0; j < CJ; j++)
 #pragma unroll
-                            for (int k = 0; k < NXK; k++)
+                            for (int k = 0; k < CK; k++)
 #pragma unroll
-                                for (int l = 0; l < NXL; l++) {
-                                    const real v = I[((i * NXJ + j) * NXK + k) * NXL + l];
-                                    kik[k] += v * djl[j * NXL + l];
-                                    kil[l] += v * djk[j * NXK + k];
-                                    kjk[j * NXK + k] += v * dil[l];
-                                    kjl[j * NXL + l] += v * dik[k];
+                                for (int l = 0; l < CL; l++) {
+                                    const real v = I[((i * CJ + j) * CK + k) * CL + l];
+                                    kik[k] += v * djl[j * CL + l];
+                                    kil[l] += v * djk[j * CK + k];
+                                    kjk[j * CK + k] += v * dil[l];
+                                    kjl[j * CL + l] += v * dik[k];
                                 }
 #pragma unroll
-                        for (int k = 0; k < NXK; k++) lds_add(&qKik[oi[i] * WK + ok[k]], (double)kik[k]);
+                        for (int k = 0; k < CK; k++) lds_add(&qKik[oi[i] * WK + ok[k]], (double)kik[k]);
 #pragma unroll
-                        for (int l = 0; l < NXL; l++) lds_add(&qKil[oi[i] * WL + ol[l]], (double)kil[l]);
+                        for (int l = 0; l < CL; l++) lds_add(&qKil[oi[i] * WL + ol[l]], (double)kil[l]);
                     }
 #pragma unroll
-                    for (int j = 0; j < NXJ; j++) {
+                    for (int j = 0; j < CJ; j++) {
 #pragma unroll
-                        for (int k = 0; k < NXK; k++) lds_add(&qKjk[oj[j] * WK + ok[k]], (double)kjk[j * NXK + k]);
+                        for (int k = 0; k < CK; k++) lds_add(&qKjk[oj[j] * WK + ok[k]], (double)kjk[j * CK + k]);
 #pragma unroll
-                        for (int l = 0; l < NXL; l++) lds_add(&qKjl[oj[j] * WL + ol[l]], (double)kjl[j * NXL + l]);
+                        for (int l = 0; l < CL; l++) lds_add(&qKjl[oj[j] * WL + ol[l]], (double)kjl[j * CL + l]);
                     }
                 }
 #endif
                 }
                 }
+                }   // chunk
             }
             }
 #else   // !QUAD

@@ -234,7 +234,8 @@ QUAD = 1 << 24                                        # (round 5: one quartet pe
                                      0x30521 | ORED, 0x21 | ORED, 0x10d21 | ORED | PAROOT,
                                      0xd21 | ORED | RSPLIT(1), 0xd21 | ORED | RSPLIT(2), 0x521 | ORED | RSPLIT(1), 0x121 | ORED | RSPLIT(1),
                                      0xd21 | ORED | PAROOT | RSPLIT(1),
-                                     0x1022 | QUAD, 0x1122 | QUAD, 0x0132 | QUAD, 0x1032 | QUAD])
+                                     0x1022 | QUAD, 0x1122 | QUAD, 0x0132 | QUAD, 0x1032 | QUAD,
+                                     0x1122 | QUAD | (1 << 25), 0x1122 | QUAD | (2 << 25) | (2 << 27)])      # (+ chunks: 2 over i, 3 over k)
 def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
     """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
     L2 | single TRR buffer | wave-local steps | j in registers | 2, 4, 8 ket pairs per iteration | owner reduction | per-root

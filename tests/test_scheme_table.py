@@ -31,7 +31,11 @@ def test_every_class_up_to_g_has_an_entry_and_obeys_the_build_rules():
             assert (v & 0xf) in (L.ALGO_TILE, L.ALGO_TILE1Q), (prec, ang, hex(v))
             assert autotune.allowed(v), (prec, ang, hex(v))         # no banned register allocation in the table
             if (v & 0xf) == L.ALGO_TILE1Q:
-                assert router.nint(ang) <= router.TILE1Q_FORCE_MAX
+                # one lane per quartet up to 200 integrals; the quad form a third of up to 330 per lane, in chunks above 180
+                assert router.nint(ang) <= (router.QUAD_FORCE_MAX if v & router.VARIANT_QUAD else router.TILE1Q_FORCE_MAX)
+                assert router.forced_variant(ang, v) == v, (prec, ang, hex(v))      # (the table holds what the class supports)
+                if v & router.VARIANT_QUAD and router.nint(ang) > 180:
+                    assert (v >> 25) & 3, (prec, ang, hex(v))
             else:
                 assert not (v & 0x3000)                              # several ket pairs: lane-per-quartet mode only
     for key, v in sch["fp64_small"].items():

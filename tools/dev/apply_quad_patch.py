@@ -40,6 +40,7 @@ constexpr int NINTQ = NXI * NXJ * NXK * NXL;              // integrals per lane
 #ifndef QY
 #define QY (-1)
 #endif
+
 static_assert(QNCH == 1 || (QY >= 0 && QY <= 3 && QY != XS), "QUAD chunks: over an index other than the split one");
 constexpr int CI = QY == 0 ? NXI / QNCH : NXI, CJ = QY == 1 ? NXJ / QNCH : NXJ, CK = QY == 2 ? NXK / QNCH : NXK, CL = QY == 3 ? NXL / QNCH : NXL;
 static_assert(CI * CJ * CK * CL * QNCH == NINTQ, "QUAD chunks must divide the component count of their index");
