@@ -162,10 +162,12 @@ int jqc_pair_table(const double* basis_d, const uint32_t* tpair_sh_d, const uint
  * ecp_terms_d[ecp_loc_d[k] .. ecp_loc_d[k + 1]) x {l (-1 = local channel), radial power n, zeta, coefficient}, i.e. the rows of
  * mol._ecpbas flattened per primitive; rgrid_d / wgrid_d: nr radial quadrature points (r, dr weight, WITHOUT r^2) on (0, inf);
  * ylm_d [25][15]: Cartesian monomial coefficients (libcint order) of the orthonormal real spherical harmonics l <= 4.
- * Shells and projectors up to l = 4, FP64 only (the reference's ECP kernels are FP64 only too, jqc/pyscf/ecp.py:51-53). */
+ * symmetric = 1: tasks with ish <= jsh, both triangles written (the value integrals); 0: only the (ish, jsh) block of every task --
+ * how the first-derivative integrals <grad a|U|b> (reference get_ecp_ip, backend/ecp.py:953-1138) are assembled from l + 1 / l - 1
+ * auxiliary bra shells appended to basis_d (joltqc_amd/backend/ecp.py).  Projectors up to l = 4, shells up to l = 5, FP64 only (the reference's ECP kernels are FP64 only too, jqc/pyscf/ecp.py:51-53). */
 int jqc_ecp_scalar(const double* basis_d, int nao, const int32_t* tasks_d, int ntasks, const double* ecp_xyz_d, const int32_t* ecp_loc_d,
                    const double* ecp_terms_d, const double* rgrid_d, const double* wgrid_d, int nr, const double* ylm_d, double* mat_d,
-                   void* stream);
+                   int symmetric, void* stream);
 
 /* One-electron integrals (overlap S, kinetic T, nuclear attraction V) of n shell pairs (ish << 16 | jsh, ish >= jsh) in the
  * internal Cartesian basis, [nao, nao] each, both triangles written.  atoms_d = [x, y, z, Z] per nucleus (Bohr).  The

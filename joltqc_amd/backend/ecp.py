@@ -6,8 +6,11 @@ order), as a device array.  Host side: tasks = (shell i <= shell j of the split 
 ``make_ecp_tasks`` (``ecp.py:1346-1369``; no screening there either), the potentials flattened per primitive from
 ``mol._ecpbas``, a radial Gauss-Chebyshev grid and the polynomial coefficients of the real spherical harmonics, both generated
 here from closed forms; then ONE launch of ``ecp_scalar_kernel`` (``csrc/ecp_kernels.inc``: what replaces the reference's
-per-(li, lj, l) JIT kernels and its tabulated angular coefficients).  Derivative integrals (``get_ecp_ip`` / ``get_ecp_ipip``,
-``ecp.py:1506-1569``) are not built.
+per-(li, lj, l) JIT kernels and its tabulated angular coefficients).  First derivatives: ``get_ecp_ip`` (``ecp.py:953-1138``: <grad a| U_C |b> per ECP atom C) through the SAME kernel -- the
+gradient of a Cartesian Gaussian shell is an (l + 1) shell with coefficients -2 alpha_p c_p plus an (l - 1) shell with the
+shell's own coefficients, so the bra shells are replaced by those auxiliary shells and the blocks are recombined on the host
+(the reference has separate ``ecp_type{1,2}_ip.cu`` kernels for Cartesian molecules and computes spherical ones on the CPU,
+``:985-1012``).  Second derivatives (``get_ecp_ipip``) are not built.
 
 Parity: the reference compares against libcint's ``ECPscalar`` (third party, absent here) and stores no numbers, so this
 row is checked against ``oracle/ecp.py`` (the definition by brute-force quadrature) only -- PARITY UNPINNED.
@@ -62,7 +65,32 @@ def ecp_arrays(mol):
     return np.asarray(xyz, dtype=float).reshape(-1, 3), np.asarray(loc, dtype=np.int32), np.asarray(terms, dtype=float).reshape(-1, 4)
 
 
-def get_ecp(mol_or_basis_layout, precision="fp64", nr=NR_DEFAULT):
+SCREEN_EXPONENT = 46.0      # tasks whose integrand is below exp(-46) = 1e-20 of its prefactors everywhere are skipped
+
+
+def screen_tasks(layout, shells, xyz, terms, loc):
+    """(shell i <= shell j, ECP atom k) triples worth evaluating.  The reference's make_ecp_tasks keeps every triple ("TODO: Add
+    screening here", ecp.py:1355); the potential is short-ranged, so for a large molecule almost all of them are empty.  Bound: with
+    the most diffuse exponents a, b of the two shells at distances d_a, d_b from the ECP atom and its most diffuse exponent z, the
+    radial integrand carries exp(-a (r - d_a)^2 - b (r - d_b)^2 - z r^2) (the Bessel functions are bounded by exp(kappa), which
+    is what turns exp(-a (r^2 + d_a^2)) into the shifted Gaussian); its exponent is smallest at r* = (a d_a + b d_b) / (a + b + z).
+    A task is dropped when that minimum exceeds SCREEN_EXPONENT."""
+    packed = np.asarray(layout.packed)
+    amin = np.array([packed[s, 5:5 + 2 * int(packed[s, 10]):2].min() for s in shells])
+    pos = packed[shells, :3]
+    i, j = np.triu_indices(len(shells))
+    out = []
+    for k in range(len(xyz)):
+        z = float(terms[loc[k]:loc[k + 1], 2].min())
+        d = np.linalg.norm(pos - xyz[k], axis=1)
+        a, b, da, db = amin[i], amin[j], d[i], d[j]
+        fmin = a * da * da + b * db * db - (a * da + b * db) ** 2 / (a + b + z)
+        keep = fmin <= SCREEN_EXPONENT
+        out.append(np.stack([shells[i[keep]], shells[j[keep]], np.full(int(keep.sum()), k)], 1))
+    return np.concatenate(out).astype(np.int32) if out else np.zeros((0, 3), np.int32)
+
+
+def get_ecp(mol_or_basis_layout, precision="fp64", nr=NR_DEFAULT, screen=True):
     import torch
     if precision != "fp64":
         raise ValueError("Only double precision ('fp64') is supported for ECP kernels")      # (reference jqc/pyscf/ecp.py:51-53)
@@ -80,9 +108,13 @@ def get_ecp(mol_or_basis_layout, precision="fp64", nr=NR_DEFAULT):
     xyz, loc, terms = ecp_arrays(mol)
     shells = np.nonzero(~np.asarray(layout.pad_id))[0]
     assert int(np.max(np.asarray(layout.angs)[shells])) <= 4, "ECP kernels: shells up to l = 4"
-    i, j = np.triu_indices(len(shells))
-    pairs = np.stack([shells[i], shells[j]], 1)
-    tasks = np.concatenate([np.concatenate([pairs, np.full((len(pairs), 1), k)], 1) for k in range(len(xyz))]).astype(np.int32)
+    if screen:
+        tasks = screen_tasks(layout, shells, xyz, terms, loc)
+    else:
+        i, j = np.triu_indices(len(shells))
+        pairs = np.stack([shells[i], shells[j]], 1)
+        tasks = np.concatenate([np.concatenate([pairs, np.full((len(pairs), 1), k)], 1) for k in range(len(xyz))]).astype(np.int32)
+    get_ecp.last_ntasks = int(tasks.shape[0])
     r, w = radial_grid(nr)
     nao = int(layout.nao)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -91,7 +123,105 @@ def get_ecp(mol_or_basis_layout, precision="fp64", nr=NR_DEFAULT):
     b64 = layout.basis_data_fp64["packed"]
     _lib.check(_lib.lib().jqc_ecp_scalar(b64.data_ptr(), nao, keep[0].data_ptr(), int(tasks.shape[0]), keep[1].data_ptr(),
                                          keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), keep[5].data_ptr(), int(nr),
-                                         keep[6].data_ptr(), mat.data_ptr(), _lib.stream_ptr()))
+                                         keep[6].data_ptr(), mat.data_ptr(), 1, _lib.stream_ptr()))
     out = layout.dm_to_mol(mat.reshape(1, nao, nao))[0]
     torch.cuda.current_stream().synchronize()          # (the temporaries above must outlive the launch)
+    return out
+
+
+def _cart(l):
+    return [(lx, ly, l - lx - ly) for lx in range(l, -1, -1) for ly in range(l - lx, -1, -1)]
+
+
+def get_ecp_ip(mol_or_basis_layout, ip_type="ip", ecp_atoms=None, precision="fp64", nr=NR_DEFAULT):
+    """``[n_ecp_atoms, 3, nao, nao]``: <d/dr a| U_C |b> for every ECP atom C (reference ``get_ecp_ip``, the per-atom blocks its tests
+    compare with libcint's ``ECPscalar_iprinv`` under ``with_rinv_at_nucleus(C)``, jqc/pyscf/tests/test_ecp_small.py:133-147), in the
+    molecule's own AO basis, spherical or Cartesian."""
+    import torch
+    if ip_type != "ip":
+        raise ValueError(f"Invalid ip_type: {ip_type}. Only 'ip' is supported.")
+    if precision != "fp64":
+        raise ValueError("Only double precision ('fp64') is supported for ECP kernels")
+    if hasattr(mol_or_basis_layout, "packed"):
+        layout, mol = mol_or_basis_layout, mol_or_basis_layout._mol
+    else:
+        from ..pyscf.basis import BasisLayout
+        mol = mol_or_basis_layout
+        layout = BasisLayout.from_mol(mol, alignment=1)
+    dev = _lib.require_gpu()
+    nao_mol = mol.nao
+    have = getattr(mol, "_ecpbas", None) is not None and len(mol._ecpbas) > 0
+    all_atoms = sorted({int(a) for a in np.asarray(mol._ecpbas)[:, 0]}) if have else []
+    want = all_atoms if ecp_atoms is None else [a for a in ecp_atoms if a in all_atoms]
+    if not want:
+        return torch.zeros((0 if ecp_atoms is None else len(ecp_atoms), 3, nao_mol, nao_mol), dtype=torch.float64, device=dev)
+    xyz, loc, terms = ecp_arrays(mol)
+    packed = np.asarray(layout.packed)
+    shells = np.nonzero(~np.asarray(layout.pad_id))[0]
+    assert int(np.max(np.asarray(layout.angs)[shells])) <= 4, "ECP kernels: shells up to l = 4"
+    nao = int(layout.nao)
+    # auxiliary bra shells: (l + 1) with coefficients alpha_p c_p (the -2 goes into the recombination), (l - 1) with c_p
+    rows, off = [packed[s].copy() for s in range(packed.shape[0])], nao
+    plus_of, minus_of = {}, {}
+    for s in shells:
+        l, npr = int(packed[s, 11]), int(packed[s, 10])
+        for dl, store in ((1, plus_of), (-1, minus_of)):
+            if l + dl < 0:
+                continue
+            r = packed[s].copy()
+            r[11] = l + dl
+            r[3] = off
+            if dl == 1:
+                r[4:4 + 2 * npr:2] = packed[s, 4:4 + 2 * npr:2] * packed[s, 5:5 + 2 * npr:2]
+            store[int(s)] = (len(rows), off)
+            rows.append(r)
+            off += (l + dl + 1) * (l + dl + 2) // 2
+    ntot = off
+    table = np.ascontiguousarray(np.stack(rows))
+    # recombination: row of d/dx_dir phi_(s, comp) = n_dir phi-_(comp - e_dir) - 2 phi+_(comp + e_dir)
+    ip_, im_ = np.zeros((3, nao), dtype=np.int64), np.full((3, nao), ntot, dtype=np.int64)      # (ntot: a row of zeros)
+    wm = np.zeros((3, nao))
+    for s in shells:
+        l, a0 = int(packed[s, 11]), int(packed[s, 3])
+        cp_, cm_ = {c: n for n, c in enumerate(_cart(l + 1))}, ({c: n for n, c in enumerate(_cart(l - 1))} if l > 0 else {})
+        for n, c in enumerate(_cart(l)):
+            for d in range(3):
+                up = tuple(c[x] + (x == d) for x in range(3))
+                ip_[d, a0 + n] = plus_of[int(s)][1] + cp_[up]
+                if c[d] > 0:
+                    dn = tuple(c[x] - (x == d) for x in range(3))
+                    im_[d, a0 + n] = minus_of[int(s)][1] + cm_[dn]
+                    wm[d, a0 + n] = c[d]
+    aux = [idx for s in shells for idx in ([plus_of[int(s)][0]] + ([minus_of[int(s)][0]] if int(s) in minus_of else []))]
+    # the distance screening of the value integrals, shell by shell (an auxiliary shell has its parent's centre and exponents)
+    parent = {plus_of[int(s)][0]: int(s) for s in shells}
+    parent.update({minus_of[int(s)][0]: int(s) for s in shells if int(s) in minus_of})
+    amin = {int(s): packed[s, 5:5 + 2 * int(packed[s, 10]):2].min() for s in shells}
+    r, w = radial_grid(nr)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tab_d, loc_d, terms_d, xyz_d, r_d, w_d, ylm_d = t(table), t(loc), t(terms), t(xyz), t(r), t(w), t(ylm_table())
+    ip_d, im_d, wm_d = t(ip_), t(im_), t(wm)
+    ecp_index = {a: k for k, a in enumerate(all_atoms)}
+    out = torch.zeros((len(want), 3, nao_mol, nao_mol), dtype=torch.float64, device=dev)
+    for n, atom in enumerate(want):
+        k = ecp_index[atom]
+        z = float(terms[loc[k]:loc[k + 1], 2].min())
+        tasks = []
+        for ia in aux:
+            sa = parent[ia]
+            da = float(np.linalg.norm(packed[sa, :3] - xyz[k]))
+            for sb in shells:
+                db = float(np.linalg.norm(packed[sb, :3] - xyz[k]))
+                a_, b_ = amin[sa], amin[int(sb)]
+                if a_ * da * da + b_ * db * db - (a_ * da + b_ * db) ** 2 / (a_ + b_ + z) <= SCREEN_EXPONENT:
+                    tasks.append((ia, int(sb), k))
+        mat = torch.zeros((ntot + 1, ntot), dtype=torch.float64, device=dev)
+        if tasks:
+            tk = t(np.asarray(tasks, dtype=np.int32))
+            _lib.check(_lib.lib().jqc_ecp_scalar(tab_d.data_ptr(), ntot, tk.data_ptr(), len(tasks), xyz_d.data_ptr(), loc_d.data_ptr(),
+                                                 terms_d.data_ptr(), r_d.data_ptr(), w_d.data_ptr(), int(nr), ylm_d.data_ptr(),
+                                                 mat.data_ptr(), 0, _lib.stream_ptr()))
+        cart = torch.stack([wm_d[d][:, None] * mat[im_d[d], :nao] - 2.0 * mat[ip_d[d], :nao] for d in range(3)])
+        out[n] = layout.dm_to_mol(cart)
+        torch.cuda.current_stream().synchronize()
     return out

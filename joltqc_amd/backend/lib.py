@@ -69,7 +69,7 @@ def lib():
         L.jqc_shell_block_max.argtypes = [vp, i32, i32, vp, i32, vp, vp]
         L.jqc_schwarz.argtypes = [i32, i32, vp, vp, i32, f64, vp, vp]
         L.jqc_int1e.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
-        L.jqc_ecp_scalar.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+        L.jqc_ecp_scalar.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
         L.jqc_gen_pair_vj_kernel.argtypes = [i32] * 6
         L.jqc_pair_ntrip.argtypes = [i32, i32]
         L.jqc_gen_jk_grad_kernel.argtypes = [i32] * 6

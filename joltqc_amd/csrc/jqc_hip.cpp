@@ -990,12 +990,12 @@ int jqc_int1e(const double* basis_d, const int32_t* ao_loc_d, const uint32_t* pa
 
 int jqc_ecp_scalar(const double* basis_d, int nao, const int32_t* tasks_d, int ntasks, const double* ecp_xyz_d, const int32_t* ecp_loc_d,
                    const double* ecp_terms_d, const double* rgrid_d, const double* wgrid_d, int nr, const double* ylm_d, double* mat_d,
-                   void* stream)
+                   int symmetric, void* stream)
 {
     if (ntasks <= 0) return 0;
     if (nr <= 0) return fail(-1, "jqc_ecp_scalar: empty radial grid");
     hipLaunchKernelGGL(ecp_scalar_kernel, dim3(ntasks), dim3(256), 0, (hipStream_t)stream, basis_d, nao, tasks_d, ecp_xyz_d, ecp_loc_d,
-                       ecp_terms_d, rgrid_d, wgrid_d, nr, ylm_d, mat_d);
+                       ecp_terms_d, rgrid_d, wgrid_d, nr, ylm_d, mat_d, symmetric);
     HIP_OK(hipGetLastError());
     return 0;
 }

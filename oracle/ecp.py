@@ -96,3 +96,34 @@ def ecp_scalar_mol(layout, mol, nang=64, nrad=48):
     V = ecp_scalar(layout, gecp.channels(mol), mol.atom_coords(), nang, nrad)
     T = layout.transform_matrix()
     return T.T @ V @ T
+
+
+def ecp_ip(layout, channels, coords_of_atom, atom, nang=64, nrad=48):
+    """<d/dr a| U_C |b> for ONE ECP atom C = ``atom``: [3, nao_int, nao_int] in the internal Cartesian AO order (what libcint's
+    ``ECPscalar_iprinv`` is for the nucleus selected by ``with_rinv_at_nucleus``; reference get_ecp_ip, backend/ecp.py:953-1138).
+    Same quadrature as ``ecp_scalar`` with the AO gradients of oracle/dft.py on the bra side."""
+    nao = int(layout.ao_loc[-1])
+    V = np.zeros((3, nao, nao))
+    r, wr = _radial(nrad)
+    ang, wang = _angular(nang)
+    C = np.asarray(coords_of_atom[atom], dtype=float)
+    by_l = {}
+    for l, power, zeta, coef in channels[atom]:
+        by_l.setdefault(l, []).append((power, zeta, coef))
+    ylm = {l: real_sph_harm(l, ang) for l in by_l if l >= 0}
+    ul = {l: _u(r, t) for l, t in by_l.items()}
+    for n in range(len(r)):
+        ao = dft.eval_ao_cart(layout.packed, layout.ao_loc, C + r[n] * ang, deriv=1)        # [4, nao, npts]
+        for x in range(3):
+            if -1 in by_l:
+                V[x] += (wr[n] * r[n] ** 2 * ul[-1][n]) * (ao[1 + x] * wang) @ ao[0].T
+            for l, y in ylm.items():
+                V[x] += (wr[n] * r[n] ** 2 * ul[l][n]) * ((ao[1 + x] * wang) @ y.T) @ ((ao[0] * wang) @ y.T).T
+    return V
+
+
+def ecp_ip_mol(layout, mol, atom, nang=64, nrad=48):
+    from joltqc_amd.gto import ecp as gecp
+    V = ecp_ip(layout, gecp.channels(mol), mol.atom_coords(), atom, nang, nrad)
+    T = layout.transform_matrix()
+    return np.einsum("pi,xpq,qj->xij", T, V, T)

@@ -60,6 +60,44 @@ def test_both_channel_types_far_and_near_the_centre():
             assert np.abs(got[sl] - ref[sl]).max() < 1e-7 * blk, (dist, name, np.abs(got[sl] - ref[sl]).max() / blk)
 
 
+@pytest.mark.parametrize("cart", [False, True])
+@pytest.mark.parametrize("kind", ["type1", "type2"])
+def test_get_ecp_ip_against_the_oracle(kind, cart):
+    """First derivatives (reference get_ecp_ip, backend/ecp.py:953-1138; its tests: test_ecp_small.py:133-147 per ECP atom against
+    libcint's ECPscalar_iprinv): <grad a| U_C |b> for each ECP atom, assembled from l + 1 / l - 1 auxiliary bra shells through the
+    value kernel, against the oracle's quadrature with the AO gradients; spherical AND Cartesian on the device (the reference
+    computes the spherical case on the CPU)."""
+    from joltqc_amd.backend import ecp as becp
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import ecp as oecp
+    mol = na2(ECP_TYPE1 if kind == "type1" else ECP_TYPE2, cart=cart)
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    got = becp.get_ecp_ip(mol).cpu().numpy()
+    assert got.shape == (2, 3, mol.nao, mol.nao)
+    for n, atom in enumerate((0, 1)):
+        ref = oecp.ecp_ip_mol(lay, mol, atom, nang=32, nrad=32)
+        scale = np.abs(ref).max()
+        assert np.abs(got[n] - ref).max() < 1e-8 * scale, (atom, np.abs(got[n] - ref).max() / scale)
+    one = becp.get_ecp_ip(mol, ecp_atoms=[1]).cpu().numpy()
+    assert one.shape == (1, 3, mol.nao, mol.nao) and np.abs(one[0] - got[1]).max() < 1e-13 * np.abs(got[1]).max()
+    with pytest.raises(ValueError):                          # (the reference's own argument check, ecp.py:969-971)
+        becp.get_ecp_ip(mol, ip_type="ipipv")
+
+
+def test_task_screening_changes_nothing():
+    """A chain of four ECP atoms 7 Bohr apart: the distance screening of the (shell pair, ECP atom) tasks (the reference keeps
+    every triple) drops most of them and leaves the matrix unchanged to 1e-14 of its largest element."""
+    from joltqc_amd.backend import ecp as becp
+    from joltqc_amd.gto import mole
+    from test_ecp_oracle import BAS
+    mol = mole.Mole(atom="; ".join(f"Na {7.0 * n} {0.3 * n} 0" for n in range(4)), basis={"Na": BAS}, ecp={"Na": ECP_TYPE2}, unit="B")
+    full = becp.get_ecp(mol, screen=False).cpu().numpy()
+    n_full = becp.get_ecp.last_ntasks
+    cut = becp.get_ecp(mol).cpu().numpy()
+    assert becp.get_ecp.last_ntasks < 0.7 * n_full, (becp.get_ecp.last_ntasks, n_full)
+    assert np.abs(cut - full).max() < 1e-14 * np.abs(full).max()
+
+
 def test_patch_interface_mirrors_the_reference():
     """jqc/pyscf/ecp.py:27-118: apply_ecp -> dict of closures, patch_ecp_integrals installs mol.get_ecp, restore removes it; a
     molecule without ECP is left alone."""

@@ -110,3 +110,29 @@ def test_oracle_is_converged_and_symmetric_on_the_reference_molecules(text):
     b = oecp.ecp_scalar_mol(lay, mol, nang=40, nrad=40)
     assert a.shape == (mol.nao, mol.nao) and np.abs(a - a.T).max() < 1e-12 * np.abs(a).max()
     assert np.abs(a - b).max() < 1e-12 * np.abs(b).max()
+
+
+def test_oracle_first_derivative_against_finite_differences():
+    """oracle.ecp.ecp_ip = <d/dr a| U_C |b>: moving the SHELLS of the other atom (the ECP centre stays) changes <a|U_C|b> by
+    -<grad a|U_C|b> . dA for a on the moved atom, b on the fixed one."""
+    import copy
+    from joltqc_amd.gto import ecp as gecp
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import ecp as oecp
+    mol = na2(ECP_TYPE2, cart=True)
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    ch = {0: gecp.channels(mol)[0]}                               # the potential of atom 0 only
+    xyz = mol.atom_coords()
+    ip = oecp.ecp_ip(lay, ch, xyz, 0, nang=32, nrad=32)
+    on1 = np.repeat(np.asarray(lay.atom_of) == 1, np.diff(lay.ao_loc))
+    h = 1e-4
+    for x in range(3):
+        vs = []
+        for sgn in (1, -1):
+            l2 = copy.copy(lay)
+            l2.packed = lay.packed.copy()
+            l2.packed[np.asarray(lay.atom_of) == 1, x] += sgn * h
+            vs.append(oecp.ecp_scalar(l2, ch, xyz, nang=32, nrad=32))
+        fd = (vs[0] - vs[1]) / (2 * h)
+        blk = np.ix_(on1, ~on1)
+        assert np.abs(fd[blk] + ip[x][blk]).max() < 1e-7 * max(np.abs(ip[x][blk]).max(), 1e-3), x
