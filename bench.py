@@ -460,15 +460,16 @@ def main():
                                          "frac": flops_by_ang.get(best, 0) / tm[best] / 1e9 / FP64_VALU_PEAK_TFLOPS}},
         }
         ar_bytes = 2 * layout.nao * layout.nao * 8
-        out["host_serial_ms"] = host_serial_ms
-        out["scaling_model"] = {
-            "host_serial_ms": host_serial_ms, "kernel_sum_ms": serial_ms, "allreduce_bytes": ar_bytes,
-            "form": "T(N) = kernel_sum_ms / N x imbalance + host_serial_ms + allreduce_ms(N)",
-            # ring all-reduce over xGMI: 2 (N - 1) / N x bytes per rank over one ~153 GB/s link direction at 70 % efficiency
-            "predicted_ms": {str(n): round(serial_ms / n * 1.1 + host_serial_ms + (0.0 if n == 1 else 2.0 * (n - 1) / n * ar_bytes / (0.7 * 153e9) * 1e3), 1)
-                             for n in (1, 2, 4, 8)},
-            "assumptions": "imbalance 1.10 (LPT split, tests/test_sharding.py: <= 10 %), ring all-reduce at 70 % of one 153 GB/s xGMI link "
-                           "direction (MI355X_MICROARCH.md); a prediction until an N > 1 node runs the bench"}
+        out["host_serial_ms"] = host_serial_ms          # (N > 1: includes this path's all-reduce; the model below is an N = 1 prediction)
+        if world == 1:
+            out["scaling_model"] = {
+                "host_serial_ms": host_serial_ms, "kernel_sum_ms": serial_ms, "allreduce_bytes": ar_bytes,
+                "form": "T(N) = kernel_sum_ms / N x imbalance + host_serial_ms + allreduce_ms(N)",
+                # ring all-reduce over xGMI: 2 (N - 1) / N x bytes per rank over one ~153 GB/s link direction at 70 % efficiency
+                "predicted_ms": {str(n): round(serial_ms / n * 1.1 + host_serial_ms + (0.0 if n == 1 else 2.0 * (n - 1) / n * ar_bytes / (0.7 * 153e9) * 1e3), 1)
+                                 for n in (1, 2, 4, 8)},
+                "assumptions": "imbalance 1.10 (LPT split, tests/test_sharding.py: <= 10 %), ring all-reduce at 70 % of one 153 GB/s xGMI link "
+                               "direction (MI355X_MICROARCH.md); a prediction until an N > 1 node runs the bench"}
         if per_rank is not None:
             out["per_rank"] = per_rank
         tr = committed_traffic(kname) if args.workload == DEFAULT_WORKLOAD else None
