@@ -155,6 +155,10 @@ int jqc_shell_block_max(const double* mat_d, int n_dm, int nao, const int32_t* a
 int jqc_pair_table(const double* basis_d, const uint32_t* tpair_sh_d, const uint32_t* tpair_wij_d,
                    const uint32_t* pp_off_d, int npairs, double* out_d, void* stream);
 
+/* Frees the library's own device scratch (today: the per-stream partial-sum buffers of the split VV10 inner loop).  Optional: the
+ * buffers are reused across calls and grow on demand; a host that unloads the library or resets the device calls this first. */
+int jqc_release_scratch(void);
+
 /* Scalar ECP integrals (replaces the kernel launches of the reference's get_ecp,
  * /root/reference/jqc/backend/ecp.py:1371-1503 -> ecp/ecp_type1.cu, ecp_type2.cu): for every task {ish, jsh, k} (ish <= jsh, ECP atom k)
  *   mat[ao_i.., ao_j..] += <i| U_L |j> + sum_l <i| U_l P_l |j>   (and the transposed block when ish != jsh), internal Cartesian AOs.

@@ -31,8 +31,9 @@ thread_local std::string g_err;
 std::mutex g_mu;
 std::string g_src_dir, g_cache_dir;
 int g_tsw[5] = {8, 4, 4, 2, 1};     // shells per tile edge by angular momentum (jqc_set_tile_widths)
-double* g_vv10_scratch = nullptr;      // per-share partial sums of the split VV10 inner loop (jqc_vv10)
-size_t g_vv10_scratch_n = 0;
+// per-share partial sums of the split VV10 inner loop (jqc_vv10), one buffer PER STREAM: calls on one stream are ordered by the
+// stream, calls on different streams (or host threads) no longer share a buffer; released by jqc_release_scratch
+std::map<void*, std::pair<double*, size_t>> g_vv10_scratch;
 std::string g_src_tag = "nosrc";   // FNV-1a of every kernel source: stale code objects are never reused
 std::string g_pair_tag = "nosrc";  // pair-based J kernels (pair_vj.hip + common headers)
 std::string g_grad_tag = "nosrc";  // same for the gradient kernels (jk_grad.hip + the headers it includes), kept apart so that
@@ -1173,6 +1174,15 @@ int jqc_dft_xcgrad(int blk0, int nblk, const int32_t* nrow_d, const int64_t* row
     return 0;
 }
 
+int jqc_release_scratch()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_vv10_scratch)
+        if (kv.second.first) (void)hipFree(kv.second.first);
+    g_vv10_scratch.clear();
+    return 0;
+}
+
 int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, const double* coords_d,
              const double* W0p_d, const double* W0_d, const double* K_d, const double* Kp_d, const double* RpW_d,
              int vvngrids, int ngrids, int fp32, void* stream)
@@ -1201,13 +1211,15 @@ int jqc_vv10(double* F_d, double* U_d, double* W_d, const double* vvcoords_d, co
         if (nsplit > 1) {
             std::lock_guard<std::mutex> lk(g_mu);
             const size_t need = (size_t)nsplit * 3 * ngrids;
-            if (g_vv10_scratch_n < need) {
-                if (g_vv10_scratch) (void)hipFree(g_vv10_scratch);
-                g_vv10_scratch = nullptr; g_vv10_scratch_n = 0;
-                HIP_OK(hipMalloc((void**)&g_vv10_scratch, need * sizeof(double)));
-                g_vv10_scratch_n = need;
+            auto& buf = g_vv10_scratch[stream];
+            if (buf.second < need) {
+                // (a buffer in use by queued kernels of this stream is released behind them: hipFree synchronises)
+                if (buf.first) (void)hipFree(buf.first);
+                buf = {nullptr, 0};
+                HIP_OK(hipMalloc((void**)&buf.first, need * sizeof(double)));
+                buf.second = need;
             }
-            out_d = g_vv10_scratch;
+            out_d = buf.first;
         }
 #define VV10_PK(N, C) hipLaunchKernelGGL((vv10_kernel_pk<N, C>), dim3(nwg, nsplit), dim3(256), 0, (hipStream_t)stream, out_d, U_d, \
                                         W_d, vvcoords_d, coords_d, W0p_d, W0_d, K_d, Kp_d, RpW_d, vvngrids, ngrids, jchunk)
