@@ -169,6 +169,10 @@ class Mole:
     def atom_symbol(self, i):
         return self._atom[i][0]
 
+    def has_ecp(self):
+        """pyscf.gto.Mole.has_ecp: does any atom carry an effective core potential?"""
+        return len(getattr(self, "_ecpbas", ())) > 0
+
     @property
     def nelectron(self):
         return int(self.atom_charges().sum()) - self.charge

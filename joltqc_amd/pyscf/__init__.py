@@ -156,7 +156,7 @@ def apply(obj, config: Optional[Dict[str, Any]] = None):
             obj._jqc_original_nuc_grad_method = original_ngm
             obj.nuc_grad_method = lambda *a, **k: _grad.patch_gradients(original_ngm(*a, **k))
 
-    if config.get("int1e") and not getattr(obj.mol, "has_ecp", lambda: False)():
+    if config.get("int1e"):
         from . import int1e as _int1e
         lay1 = BasisLayout.from_mol(obj.mol, alignment=1)
         # (bound like the originals: mf.get_hcore(mol=None), mf.get_ovlp(mol=None))

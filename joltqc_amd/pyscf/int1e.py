@@ -6,7 +6,8 @@ evaluated on the split shells of the ``BasisLayout`` and folded back to the mole
 as J/K (``V_mol = T^T V_int T``), so contracted shells cut into <= 3-primitive pieces add up correctly.
 
     S, T, V = int1e(layout, mol)                         # device tensors [nao_mol, nao_mol]
-    apply(mf, {**get_default_config(), "int1e": True})   # mf.get_hcore / mf.get_ovlp from the device (NumPy out on a CPU object)
+    apply(mf, {**get_default_config(), "int1e": True})   # mf.get_hcore / mf.get_ovlp from the device (NumPy out on a CPU object;
+                                                         #  a molecule with ECPs gets the device ECP matrix added to h_core)
 """
 import numpy as np
 
@@ -40,9 +41,16 @@ def int1e(layout, mol=None):
 
 
 def generate_get_hcore(layout, numpy_out=True):
+    """``mf.get_hcore(mol=None)``: T + V_nuc, plus the scalar ECP matrix of a molecule that carries effective core potentials --
+    what ``pyscf.scf.hf.get_hcore`` adds through ``mol.intor("ECPscalar")``; here from ``backend.ecp.get_ecp`` (the nuclear
+    charges in ``mol._atm`` are already lowered by the core electrons, as PySCF lowers them)."""
     def get_hcore(mol=None):
         _, T, V = int1e(layout, mol)
         h = T + V
+        m = mol if mol is not None else layout._mol
+        if len(getattr(m, "_ecpbas", ())) > 0:
+            from ..backend import ecp as _ecp
+            h = h + _ecp.get_ecp(layout)
         return h.cpu().numpy() if numpy_out else h
     return get_hcore
 

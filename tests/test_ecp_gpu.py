@@ -98,6 +98,33 @@ def test_task_screening_changes_nothing():
     assert np.abs(cut - full).max() < 1e-14 * np.abs(full).max()
 
 
+def test_rhf_with_ecp_through_apply_with_device_integrals():
+    """The row in use: RHF on Na2 with the reference's type-2 potential (two valence electrons) through ``apply()`` with
+    ``int1e=True`` -- overlap, kinetic energy, nuclear attraction of the lowered charges AND the ECP matrix from the device, J / K
+    from the tiled kernels up to (gg|gg) -- against the same SCF with every integral from the CPU oracles."""
+    import joltqc_amd.pyscf as jp
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import dense
+    from oracle import ecp as oecp
+    from standin_scf import RHF
+    mol = na2(ECP_TYPE2)
+    assert mol.has_ecp() and mol.nelectron == 2
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    S, T, V = dense.int1e_mol(lay, mol)
+    h_ref = T + V + oecp.ecp_scalar_mol(lay, mol, nang=32, nrad=32)
+    ref = RHF(mol, h_ref, S)
+    q = dense.canonical_quartets(lay)
+    ref.get_jk = lambda mol_=None, dm=None, hermi=1, **kw: dense.get_jk(lay, dm, hermi, quartets=q)
+    e_ref = ref.kernel()
+    cfg = jp.get_default_config()
+    cfg["int1e"] = True
+    mf = jp.apply(RHF(mol, None, None), cfg)
+    mf._hcore, mf._ovlp = mf.get_hcore(), mf.get_ovlp()
+    assert np.abs(mf._hcore - h_ref).max() < 1e-8 * np.abs(h_ref).max()
+    e = mf.kernel()
+    assert ref.converged and mf.converged and abs(e - e_ref) < 1e-8, (e, e_ref)
+
+
 def test_patch_interface_mirrors_the_reference():
     """jqc/pyscf/ecp.py:27-118: apply_ecp -> dict of closures, patch_ecp_integrals installs mol.get_ecp, restore removes it; a
     molecule without ECP is left alone."""
