@@ -31,7 +31,7 @@ def get_default_config() -> Dict[str, Any]:
         # not in the reference, which drives one device
         "parallel": False,
         # True: mf.get_hcore / mf.get_ovlp from the device kernels (joltqc_amd/pyscf/int1e.py) instead of the object's own
-        # (PySCF: libcint on the CPU); objects with ECPs keep their own
+        # (PySCF: libcint on the CPU); a molecule with ECPs gets the device ECP matrix added to h_core (backend/ecp.py)
         "int1e": False,
         # True: RHF objects with ``nuc_grad_method`` (PySCF) get gradient objects whose ``grad_elec`` takes the two-electron term
         # from the device kernels (joltqc_amd/pyscf/grad.py).  ``obj._jqc_jk_energy_per_atom`` is installed
