@@ -374,6 +374,7 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
         cut64, tol = (1e20, 2e-5) if mode == "fused32" else (30.0, 2e-5)
     bad, nclass, nfused, nboth = [], 0, 0, 0
     lmax = 3 if dm.ndim == 3 and dm.shape[0] == 3 else 4      # (three matrices: s..f, the odd-tail logic is the same for g)
+    get_jk = jkmod.generate_jk_kernel(lay, cutoff_fp64=cut64, cutoff_fp32=1e-13)
     try:
         for li in range(lmax + 1):
             for lj in range(li + 1):
@@ -390,8 +391,7 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
                         if ck not in _CLASS_ORACLE:
                             _CLASS_ORACLE[ck] = dense.get_jk(lay, dm, hermi=1, quartets=allq[sel], omega=omega)
                         rj, rk = _CLASS_ORACLE[ck]
-                        os.environ["JQC_ONLY_CLASS"] = key
-                        get_jk = jkmod.generate_jk_kernel(lay, cutoff_fp64=cut64, cutoff_fp32=1e-13)
+                        os.environ["JQC_ONLY_CLASS"] = key          # (read by get_jk at call time: one closure, one plan for all classes)
                         vj, vk = get_jk(mol, dm, hermi=1, with_j=with_j, with_k=with_k, omega=omega)
                         sc = max(np.abs(rj).max() if with_j else 0.0, np.abs(rk).max() if with_k else 0.0)
                         err = max(np.abs(_np(vj) - rj).max() if with_j else 0.0, np.abs(_np(vk) - rk).max() if with_k else 0.0) / sc
