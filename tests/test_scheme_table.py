@@ -65,6 +65,27 @@ def test_forced_variant_respects_what_a_class_supports():
     assert not router.forced_variant((3, 3, 1, 0), 0x421) & 0x400             # 100 row lanes do not
 
 
+def test_quad_variants_only_where_the_class_supports_them():
+    """JQC_VARIANT_QUAD (bit 24) needs a lane-per-quartet build of a class with a p shell and at most four Rys roots; the chunk bits
+    (25-28, JQC_VARIANT_QCHUNK) a shell other than the split p shell whose component count the chunk count divides."""
+    Q = router.VARIANT_QUAD
+    assert router.forced_variant((2, 1, 1, 1), 0x1122 | Q) == 0x1122 | Q
+    assert router.forced_variant((2, 0, 2, 0), 0x1122 | Q) == 0x1122                  # no p shell
+    assert router.forced_variant((3, 3, 1, 1), 0x1122 | Q) == L.ALGO_TILE             # 900 integrals: row lanes
+    assert router.forced_variant((2, 2, 1, 1), 0x1122 | Q) & Q                        # 324 integrals, 4 roots: allowed (spills; chunks help)
+    assert router.forced_variant((2, 1, 1, 1), 0x21 | Q) == 0x21                      # row-lane algorithm: bit dropped
+    two_over_i, three_over_k = router.VARIANT_QCHUNK(1, 0), router.VARIANT_QCHUNK(2, 2)
+    assert router.forced_variant((2, 1, 2, 1), 0x1122 | Q | two_over_i) == 0x1122 | Q | two_over_i      # d shell: 6 components, 2 chunks
+    assert router.forced_variant((1, 1, 1, 1), 0x1122 | Q | two_over_i) == 0x1122 | Q                   # p shell: 3 components, not by 2
+    assert router.forced_variant((2, 1, 2, 1), 0x1122 | Q | three_over_k) == 0x1122 | Q | three_over_k
+    assert router.forced_variant((2, 2, 1, 0), 0x1122 | Q | three_over_k) == 0x1122 | Q                 # k IS the split p shell
+    assert router.forced_variant((2, 1, 1, 1), 0x1122 | two_over_i) == 0x1122                            # chunks without the quad bit
+    assert not router.supports_mixed((2, 1, 1, 1), 0x1122 | Q) and router.supports_ndm2((2, 1, 1, 1), 0x1122 | Q)
+    # the table's quad entries: (dp|dp) in three chunks over its bra d shell, (fp|pp) in two over its f shell
+    assert router.select_algo((2, 1, 2, 1)) == 0x1001122 | router.VARIANT_QCHUNK(2, 0)
+    assert router.select_algo((3, 1, 1, 1)) == 0x1001122 | router.VARIANT_QCHUNK(1, 0)
+
+
 def test_too_many_ket_pairs_degrade_to_fewer(tmp_path, monkeypatch):
     """(dp|ps) with 8 ket pairs per iteration needs > 160 KB of LDS: the router retries with 4 (still the HIP path)."""
     with pytest.raises(RuntimeError):
