@@ -225,3 +225,39 @@ def get_ecp_ip(mol_or_basis_layout, ip_type="ip", ecp_atoms=None, precision="fp6
         out[n] = layout.dm_to_mol(cart)
         torch.cuda.current_stream().synchronize()
     return out
+
+
+def ecp_energy_per_atom(mol_or_basis_layout, dm, nr=NR_DEFAULT):
+    """``[natm, 3]``: d/dR tr(D h_ECP) at fixed density matrix (the ECP term of a nuclear gradient, in the form the two-electron
+    term is offered by ``joltqc_amd.pyscf.grad``; the reference leaves forces to GPU4PySCF, which builds this from the same
+    ``ECPscalar_iprinv`` blocks, cf. jqc/backend/ecp.py:953-968).  With ip_C = <grad a| U_C |b> (``get_ecp_ip``) and a symmetric D:
+    moving the shells of atom R contributes -2 sum_{a on R} sum_b D_ab ip_C[a, b] for every ECP atom C, and moving the potential of
+    C itself, by translational invariance, +2 sum_ab D_ab ip_C[a, b]."""
+    import torch
+    if hasattr(mol_or_basis_layout, "packed"):
+        layout, mol = mol_or_basis_layout, mol_or_basis_layout._mol
+    else:
+        from ..pyscf.basis import BasisLayout
+        mol = mol_or_basis_layout
+        layout = BasisLayout.from_mol(mol, alignment=1)
+    dev = _lib.require_gpu()
+    natm = int(mol.natm)
+    out = torch.zeros((natm, 3), dtype=torch.float64, device=dev)
+    if getattr(mol, "_ecpbas", None) is None or len(mol._ecpbas) == 0:
+        return out
+    d = torch.as_tensor(np.asarray(dm) if not torch.is_tensor(dm) else dm, dtype=torch.float64, device=dev)
+    d = 0.5 * (d + d.T)
+    ip = get_ecp_ip(layout, nr=nr)                                          # [n_ecp, 3, nao, nao]
+    ecp_atoms = sorted({int(a) for a in np.asarray(mol._ecpbas)[:, 0]})
+    # atom of every AO of the molecule's own basis
+    bas = np.asarray(mol._bas)
+    loc = np.asarray(mol.ao_loc_nr())
+    ao_atom = np.concatenate([np.full(int(loc[i + 1] - loc[i]), int(bas[i, 0])) for i in range(bas.shape[0])])
+    onehot = torch.zeros((natm, d.shape[0]), dtype=torch.float64, device=dev)
+    onehot[torch.from_numpy(ao_atom).to(dev), torch.arange(d.shape[0], device=dev)] = 1.0
+    rows = torch.einsum("cxab,ab->cxa", ip, d)                              # sum over b, per bra AO
+    out -= 2.0 * torch.einsum("ra,cxa->rx", onehot, rows)
+    tot = rows.sum(dim=2)                                                   # [n_ecp, 3]
+    for n, c in enumerate(ecp_atoms):
+        out[c] += 2.0 * tot[n]
+    return out

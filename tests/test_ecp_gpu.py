@@ -84,6 +84,34 @@ def test_get_ecp_ip_against_the_oracle(kind, cart):
         becp.get_ecp_ip(mol, ip_type="ipipv")
 
 
+def test_ecp_force_term_against_finite_differences():
+    """d/dR tr(D h_ECP) at fixed D from the first-derivative blocks (translational invariance for the ECP centre itself)
+    against central differences of the device's own value integrals, every atom and direction of a bent three-atom molecule
+    with one ECP atom."""
+    from joltqc_amd.backend import ecp as becp
+    from joltqc_amd.gto import mole
+    bas = {"Na": [[0, [4.0, 0.5], [0.6, 0.6]], [1, [1.2, 1.0]], [2, [0.8, 1.0]]], "H": [[0, [1.1, 1.0]], [1, [0.9, 1.0]]]}
+    text = "Na nelec 10\nNa ul\n2 0.9 0.7\n1 1.8 -1.1\nNa S\n2 3.0 25.0\nNa P\n2 2.1 9.0\n"
+    xyz = np.array([[0.0, 0.1, -0.2], [2.3, 0.4, 0.3], [-0.9, 2.0, 0.8]])
+    build = lambda r: mole.Mole(atom=[("Na", r[0]), ("H", r[1]), ("H", r[2])], basis=bas, ecp={"Na": text}, unit="B")
+    mol = build(xyz)
+    rng = np.random.default_rng(3)
+    D = rng.random((mol.nao, mol.nao)) - 0.5
+    D = D + D.T
+    g = becp.ecp_energy_per_atom(mol, D).cpu().numpy()
+    energy = lambda r: float((becp.get_ecp(build(r)).cpu().numpy() * D).sum())
+    h = 2e-4
+    fd = np.zeros((3, 3))
+    for a in range(3):
+        for x in range(3):
+            rp, rm = xyz.copy(), xyz.copy()
+            rp[a, x] += h
+            rm[a, x] -= h
+            fd[a, x] = (energy(rp) - energy(rm)) / (2 * h)
+    assert np.abs(g.sum(0)).max() < 1e-10 * np.abs(g).max()               # translational invariance
+    assert np.abs(g - fd).max() < 1e-6 * np.abs(fd).max(), (g, fd)
+
+
 def test_task_screening_changes_nothing():
     """A chain of four ECP atoms 7 Bohr apart: the distance screening of the (shell pair, ECP atom) tasks (the reference keeps
     every triple) drops most of them and leaves the matrix unchanged to 1e-14 of its largest element."""
