@@ -168,10 +168,12 @@ int jqc_release_scratch(void);
  * ylm_d [25][15]: Cartesian monomial coefficients (libcint order) of the orthonormal real spherical harmonics l <= 4.
  * symmetric = 1: tasks with ish <= jsh, both triangles written (the value integrals); 0: only the (ish, jsh) block of every task --
  * how the first-derivative integrals <grad a|U|b> (reference get_ecp_ip, backend/ecp.py:953-1138) are assembled from l + 1 / l - 1
- * auxiliary bra shells appended to basis_d (joltqc_amd/backend/ecp.py).  Projectors up to l = 4, shells up to l = 5, FP64 only (the reference's ECP kernels are FP64 only too, jqc/pyscf/ecp.py:51-53). */
+ * auxiliary bra shells appended to basis_d (joltqc_amd/backend/ecp.py).  lmax_shell = largest l in basis_d: up to 5 the kernel instance
+ * with three radial points per chunk runs, 6 (l + 2 shells of the second derivatives, get_ecp_ipip) the one with two.  Projectors up to
+ * l = 4, FP64 only (the reference's ECP kernels are FP64 only too, jqc/pyscf/ecp.py:51-53). */
 int jqc_ecp_scalar(const double* basis_d, int nao, const int32_t* tasks_d, int ntasks, const double* ecp_xyz_d, const int32_t* ecp_loc_d,
                    const double* ecp_terms_d, const double* rgrid_d, const double* wgrid_d, int nr, const double* ylm_d, double* mat_d,
-                   int symmetric, void* stream);
+                   int symmetric, int lmax_shell, void* stream);
 
 /* One-electron integrals (overlap S, kinetic T, nuclear attraction V) of n shell pairs (ish << 16 | jsh, ish >= jsh) in the
  * internal Cartesian basis, [nao, nao] each, both triangles written.  atoms_d = [x, y, z, Z] per nucleus (Bohr).  The

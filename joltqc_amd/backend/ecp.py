@@ -10,7 +10,9 @@ per-(li, lj, l) JIT kernels and its tabulated angular coefficients).  First deri
 gradient of a Cartesian Gaussian shell is an (l + 1) shell with coefficients -2 alpha_p c_p plus an (l - 1) shell with the
 shell's own coefficients, so the bra shells are replaced by those auxiliary shells and the blocks are recombined on the host
 (the reference has separate ``ecp_type{1,2}_ip.cu`` kernels for Cartesian molecules and computes spherical ones on the CPU,
-``:985-1012``).  Second derivatives (``get_ecp_ipip``) are not built.
+``:985-1012``).  Second derivatives ``get_ecp_ipip`` (``ecp.py:1141-1340``: <grad grad a| U_C |b>
+("ipipv") and <grad a| U_C |grad b> ("ipvip")) the same way with (l + 2, alpha^2 c), (l, alpha c), (l - 2, c) auxiliary shells, or l +- 1
+shells on both sides.
 
 Parity: the reference compares against libcint's ``ECPscalar`` (third party, absent here) and stores no numbers, so this
 row is checked against ``oracle/ecp.py`` (the definition by brute-force quadrature) only -- PARITY UNPINNED.
@@ -123,7 +125,7 @@ def get_ecp(mol_or_basis_layout, precision="fp64", nr=NR_DEFAULT, screen=True):
     b64 = layout.basis_data_fp64["packed"]
     _lib.check(_lib.lib().jqc_ecp_scalar(b64.data_ptr(), nao, keep[0].data_ptr(), int(tasks.shape[0]), keep[1].data_ptr(),
                                          keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), keep[5].data_ptr(), int(nr),
-                                         keep[6].data_ptr(), mat.data_ptr(), 1, _lib.stream_ptr()))
+                                         keep[6].data_ptr(), mat.data_ptr(), 1, 4, _lib.stream_ptr()))
     out = layout.dm_to_mol(mat.reshape(1, nao, nao))[0]
     torch.cuda.current_stream().synchronize()          # (the temporaries above must outlive the launch)
     return out
@@ -220,7 +222,7 @@ def get_ecp_ip(mol_or_basis_layout, ip_type="ip", ecp_atoms=None, precision="fp6
             tk = t(np.asarray(tasks, dtype=np.int32))
             _lib.check(_lib.lib().jqc_ecp_scalar(tab_d.data_ptr(), ntot, tk.data_ptr(), len(tasks), xyz_d.data_ptr(), loc_d.data_ptr(),
                                                  terms_d.data_ptr(), r_d.data_ptr(), w_d.data_ptr(), int(nr), ylm_d.data_ptr(),
-                                                 mat.data_ptr(), 0, _lib.stream_ptr()))
+                                                 mat.data_ptr(), 0, 5, _lib.stream_ptr()))
         cart = torch.stack([wm_d[d][:, None] * mat[im_d[d], :nao] - 2.0 * mat[ip_d[d], :nao] for d in range(3)])
         out[n] = layout.dm_to_mol(cart)
         torch.cuda.current_stream().synchronize()
@@ -260,4 +262,149 @@ def ecp_energy_per_atom(mol_or_basis_layout, dm, nr=NR_DEFAULT):
     tot = rows.sum(dim=2)                                                   # [n_ecp, 3]
     for n, c in enumerate(ecp_atoms):
         out[c] += 2.0 * tot[n]
+    return out
+
+
+_AUX = {"p1": (1, 1), "m1": (-1, 0), "p2": (2, 2), "z0": (0, 1), "m2": (-2, 0)}      # kind -> (l shift, power of alpha in the coefficients)
+
+
+def _aux_shells(packed, shells, kinds, first_ao):
+    """Auxiliary shell rows for the derivative integrals: for every shell s and kind k a row with l + dl and coefficients
+    alpha_p^n c_p, AOs appended after ``first_ao``.  Returns (rows, {(s, kind): (row index counted from len(packed), first AO)}, next AO)."""
+    rows, where, off = [], {}, first_ao
+    for s in shells:
+        l, npr = int(packed[s, 11]), int(packed[s, 10])
+        for kind in kinds:
+            dl, na = _AUX[kind]
+            if l + dl < 0:
+                continue
+            r = packed[s].copy()
+            r[11], r[3] = l + dl, off
+            r[4:4 + 2 * npr:2] = packed[s, 4:4 + 2 * npr:2] * packed[s, 5:5 + 2 * npr:2] ** na
+            where[(int(s), kind)] = (len(rows), off)
+            rows.append(r)
+            off += (l + dl + 1) * (l + dl + 2) // 2
+    return rows, where, off
+
+
+def _terms(l, comp, i, j=None):
+    """d/dx_i (j None) or d^2/dx_i dx_j of the Cartesian Gaussian component ``comp`` (exponents) of an l shell as a list of
+    (weight, kind, exponents of the auxiliary shell's component)."""
+    n = list(comp)
+    sh = lambda d: tuple(n[x] + d[x] for x in range(3))
+    e = lambda x, v: tuple(v if y == x else 0 for y in range(3))
+    if j is None:
+        out = [(-2.0, "p1", sh(e(i, 1)))]
+        if n[i] > 0:
+            out.append((float(n[i]), "m1", sh(e(i, -1))))
+        return out
+    if i == j:
+        out = [(4.0, "p2", sh(e(i, 2))), (-2.0 * (2 * n[i] + 1), "z0", tuple(n))]
+        if n[i] > 1:
+            out.append((float(n[i] * (n[i] - 1)), "m2", sh(e(i, -2))))
+        return out
+    pp = tuple(n[x] + (x == i) + (x == j) for x in range(3))
+    out = [(4.0, "p2", pp)]
+    if n[j] > 0:
+        out.append((-2.0 * n[j], "z0", tuple(n[x] + (x == i) - (x == j) for x in range(3))))
+    if n[i] > 0:
+        out.append((-2.0 * n[i], "z0", tuple(n[x] - (x == i) + (x == j) for x in range(3))))
+    if n[i] > 0 and n[j] > 0:
+        out.append((float(n[i] * n[j]), "m2", tuple(n[x] - (x == i) - (x == j) for x in range(3))))
+    return out
+
+
+def get_ecp_ipip(mol_or_basis_layout, ip_type="ipipv", ecp_atoms=None, precision="fp64", nr=NR_DEFAULT):
+    """``[n_ecp_atoms, 9, nao, nao]`` (component 3 i + j): "ipipv" = <d_i d_j a| U_C |b>, "ipvip" = <d_i a| U_C |d_j b>, per ECP atom C
+    (reference ``get_ecp_ipip``, backend/ecp.py:1141-1340; libcint's ``ECPscalar_ipiprinv`` / ``ECPscalar_iprinvip``), from the value
+    kernel on auxiliary shells (module docstring); g shells need its l <= 6 instantiation."""
+    import torch
+    if ip_type not in ("ipipv", "ipvip"):
+        raise ValueError(f"Invalid ip_type: {ip_type}. Supported types: 'ipipv', 'ipvip'")
+    if precision != "fp64":
+        raise ValueError("Only double precision ('fp64') is supported for ECP kernels")
+    if hasattr(mol_or_basis_layout, "packed"):
+        layout, mol = mol_or_basis_layout, mol_or_basis_layout._mol
+    else:
+        from ..pyscf.basis import BasisLayout
+        mol = mol_or_basis_layout
+        layout = BasisLayout.from_mol(mol, alignment=1)
+    dev = _lib.require_gpu()
+    nao_mol = mol.nao
+    have = getattr(mol, "_ecpbas", None) is not None and len(mol._ecpbas) > 0
+    all_atoms = sorted({int(a) for a in np.asarray(mol._ecpbas)[:, 0]}) if have else []
+    want = all_atoms if ecp_atoms is None else [a for a in ecp_atoms if a in all_atoms]
+    if not want:
+        return torch.zeros((0 if ecp_atoms is None else len(ecp_atoms), 9, nao_mol, nao_mol), dtype=torch.float64, device=dev)
+    xyz, loc, terms = ecp_arrays(mol)
+    packed = np.asarray(layout.packed)
+    shells = [int(s) for s in np.nonzero(~np.asarray(layout.pad_id))[0]]
+    assert max(int(packed[s, 11]) for s in shells) <= 4, "ECP kernels: shells up to l = 4"
+    nao = int(layout.nao)
+    bra_kinds = ("p2", "z0", "m2") if ip_type == "ipipv" else ("p1", "m1")
+    rows_a, where_a, off = _aux_shells(packed, shells, bra_kinds, nao)
+    rows_b, where_b, off = _aux_shells(packed, shells, ("p1", "m1") if ip_type == "ipvip" else (), off)
+    ntot = off
+    table = np.ascontiguousarray(np.stack([packed[s] for s in range(packed.shape[0])] + rows_a + rows_b))
+    base_a, base_b = packed.shape[0], packed.shape[0] + len(rows_a)
+    lmax_shell = int(table[:, 11].max())
+    cidx = {l: {c: n for n, c in enumerate(_cart(l))} for l in range(0, 7)}
+
+    def side(where, i=None, j=None):
+        """per Cartesian AO row of the internal basis: list of (weight, source row in the combined AO space) for d_i (d_j)"""
+        lists = [[] for _ in range(nao)]
+        for s in shells:
+            l, a0 = int(packed[s, 11]), int(packed[s, 3])
+            for n, c in enumerate(_cart(l)):
+                for wgt, kind, ex in _terms(l, c, i, j):
+                    lists[a0 + n].append((wgt, where[(s, kind)][1] + cidx[l + _AUX[kind][0]][ex]))
+        width = max(len(x) for x in lists)
+        idx = np.full((width, nao), ntot, dtype=np.int64)                 # (ntot: a row / column of zeros)
+        wts = np.zeros((width, nao))
+        for r, x in enumerate(lists):
+            for t, (wgt, src) in enumerate(x):
+                idx[t, r], wts[t, r] = src, wgt
+        return torch.from_numpy(idx).to(dev), torch.from_numpy(wts).to(dev)
+
+    r, w = radial_grid(nr)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tab_d, loc_d, terms_d, xyz_d, r_d, w_d, ylm_d = t(table), t(loc), t(terms), t(xyz), t(r), t(w), t(ylm_table())
+    amin = {s: packed[s, 5:5 + 2 * int(packed[s, 10]):2].min() for s in shells}
+    bra_rows = [(base_a + where_a[key][0], key[0]) for key in where_a]
+    ket_rows = [(base_b + where_b[key][0], key[0]) for key in where_b] if ip_type == "ipvip" else [(s, s) for s in shells]
+    ecp_index = {a: k for k, a in enumerate(all_atoms)}
+    out = torch.zeros((len(want), 9, nao_mol, nao_mol), dtype=torch.float64, device=dev)
+    if ip_type == "ipipv":
+        sides = {(i, j): side(where_a, i, j) for i in range(3) for j in range(3)}
+    else:
+        sa = {i: side(where_a, i) for i in range(3)}
+        sb = {j: side(where_b, j) for j in range(3)}
+    for n, atom in enumerate(want):
+        k = ecp_index[atom]
+        z = float(terms[loc[k]:loc[k + 1], 2].min())
+        dist = {s: float(np.linalg.norm(packed[s, :3] - xyz[k])) for s in shells}
+        tasks = [(ra, rb, k) for ra, pa in bra_rows for rb, pb in ket_rows
+                 if amin[pa] * dist[pa] ** 2 + amin[pb] * dist[pb] ** 2
+                 - (amin[pa] * dist[pa] + amin[pb] * dist[pb]) ** 2 / (amin[pa] + amin[pb] + z) <= SCREEN_EXPONENT]
+        mat = torch.zeros((ntot + 1, ntot + 1), dtype=torch.float64, device=dev)
+        if tasks:
+            tk = t(np.asarray(tasks, dtype=np.int32))
+            _lib.check(_lib.lib().jqc_ecp_scalar(tab_d.data_ptr(), ntot + 1, tk.data_ptr(), len(tasks), xyz_d.data_ptr(), loc_d.data_ptr(),
+                                                 terms_d.data_ptr(), r_d.data_ptr(), w_d.data_ptr(), int(nr), ylm_d.data_ptr(),
+                                                 mat.data_ptr(), 0, lmax_shell, _lib.stream_ptr()))
+        comps = []
+        for i in range(3):
+            for j in range(3):
+                if ip_type == "ipipv":
+                    ia, wa = sides[(i, j)]
+                    comps.append(sum(wa[q][:, None] * mat[ia[q], :nao] for q in range(ia.shape[0])))
+                else:
+                    (ia, wa), (ib, wb) = sa[i], sb[j]
+                    acc = 0
+                    for q in range(ia.shape[0]):
+                        for p in range(ib.shape[0]):
+                            acc = acc + (wa[q][:, None] * wb[p][None, :]) * mat[ia[q]][:, ib[p]]
+                    comps.append(acc)
+        out[n] = layout.dm_to_mol(torch.stack(comps))
+        torch.cuda.current_stream().synchronize()
     return out

@@ -30,11 +30,11 @@ _rys_uploaded = False
 
 def build_library(force=False):
     """hipcc-compile the C-ABI library in-tree (cross-compiles for gfx950 without a GPU)."""
+    import glob
     src = os.path.join(CSRC, "jqc_hip.cpp")
-    inc = os.path.join(CSRC, "dft_kernels.inc")
     hdr = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "jqc_hip.h")
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(inc))):
+    deps = [src, hdr] + glob.glob(os.path.join(CSRC, "*.inc"))          # (dft_kernels.inc, ecp_kernels.inc, ecp_kernel_body.inc)
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in deps):
         return LIB_PATH
     cmd = ["hipcc", "-O2", "-shared", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", src,
            "-o", LIB_PATH, "-lhiprtc"]
@@ -69,7 +69,7 @@ def lib():
         L.jqc_shell_block_max.argtypes = [vp, i32, i32, vp, i32, vp, vp]
         L.jqc_schwarz.argtypes = [i32, i32, vp, vp, i32, f64, vp, vp]
         L.jqc_int1e.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
-        L.jqc_ecp_scalar.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
+        L.jqc_ecp_scalar.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp]
         L.jqc_gen_pair_vj_kernel.argtypes = [i32] * 6
         L.jqc_pair_ntrip.argtypes = [i32, i32]
         L.jqc_gen_jk_grad_kernel.argtypes = [i32] * 6

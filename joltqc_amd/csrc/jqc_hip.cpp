@@ -991,12 +991,18 @@ int jqc_int1e(const double* basis_d, const int32_t* ao_loc_d, const uint32_t* pa
 
 int jqc_ecp_scalar(const double* basis_d, int nao, const int32_t* tasks_d, int ntasks, const double* ecp_xyz_d, const int32_t* ecp_loc_d,
                    const double* ecp_terms_d, const double* rgrid_d, const double* wgrid_d, int nr, const double* ylm_d, double* mat_d,
-                   int symmetric, void* stream)
+                   int symmetric, int lmax_shell, void* stream)
 {
     if (ntasks <= 0) return 0;
     if (nr <= 0) return fail(-1, "jqc_ecp_scalar: empty radial grid");
-    hipLaunchKernelGGL(ecp_scalar_kernel, dim3(ntasks), dim3(256), 0, (hipStream_t)stream, basis_d, nao, tasks_d, ecp_xyz_d, ecp_loc_d,
-                       ecp_terms_d, rgrid_d, wgrid_d, nr, ylm_d, mat_d, symmetric);
+    if (lmax_shell > 6) return fail(-1, "jqc_ecp_scalar: shells up to l = 6 (second derivatives of g shells)");
+    // two instantiations of the kernel (ecp_kernels.inc): shells up to h with three radial points per chunk, up to i with two
+    if (lmax_shell <= 5)
+        hipLaunchKernelGGL(ecp_scalar_kernel_l5, dim3(ntasks), dim3(256), 0, (hipStream_t)stream, basis_d, nao, tasks_d, ecp_xyz_d,
+                           ecp_loc_d, ecp_terms_d, rgrid_d, wgrid_d, nr, ylm_d, mat_d, symmetric);
+    else
+        hipLaunchKernelGGL(ecp_scalar_kernel_l6, dim3(ntasks), dim3(256), 0, (hipStream_t)stream, basis_d, nao, tasks_d, ecp_xyz_d,
+                           ecp_loc_d, ecp_terms_d, rgrid_d, wgrid_d, nr, ylm_d, mat_d, symmetric);
     HIP_OK(hipGetLastError());
     return 0;
 }

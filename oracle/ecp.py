@@ -127,3 +127,74 @@ def ecp_ip_mol(layout, mol, atom, nang=64, nrad=48):
     V = ecp_ip(layout, gecp.channels(mol), mol.atom_coords(), atom, nang, nrad)
     T = layout.transform_matrix()
     return np.einsum("pi,xpq,qj->xij", T, V, T)
+
+
+def ao_second_derivatives(packed, ao_loc, coords):
+    """d^2 phi / dx_i dx_j of the internal Cartesian AOs on ``coords``: [3, 3, nao_int, npts].  Each AO is a sum over primitives of
+    products of 1-D factors g(x) = x^n exp(-a x^2), differentiated factor by factor (checked against central differences of
+    oracle/dft.py's first derivatives in tests/test_ecp_oracle.py)."""
+    packed = np.asarray(packed, dtype=float)
+    coords = np.asarray(coords, dtype=float)
+    nao, ng = int(ao_loc[-1]), coords.shape[0]
+    out = np.zeros((3, 3, nao, ng))
+
+    def g(x, n, a, order):
+        e = np.exp(-a * x * x)
+        pw = lambda k: x ** k if k > 0 else (np.ones_like(x) if k == 0 else np.zeros_like(x))
+        if order == 0:
+            return pw(n) * e
+        if order == 1:
+            return (n * pw(n - 1) - 2 * a * pw(n + 1)) * e
+        return (n * (n - 1) * pw(n - 2) - 2 * a * (2 * n + 1) * pw(n) + 4 * a * a * pw(n + 2)) * e
+
+    for s in range(packed.shape[0]):
+        if ao_loc[s + 1] == ao_loc[s]:
+            continue
+        l, npr = int(packed[s, 11]), int(packed[s, 10])
+        r = coords - packed[s, :3]
+        for n, pows in enumerate(dft.cart_powers(l)):
+            for p in range(npr):
+                c, a = packed[s, 4 + 2 * p], packed[s, 5 + 2 * p]
+                f = [[g(r[:, d], pows[d], a, o) for o in range(3)] for d in range(3)]
+                for i in range(3):
+                    for j in range(3):
+                        order = [(d == i) + (d == j) for d in range(3)]
+                        out[i, j, ao_loc[s] + n] += c * f[0][order[0]] * f[1][order[1]] * f[2][order[2]]
+    return out
+
+
+def ecp_ipip(layout, channels, coords_of_atom, atom, ip_type="ipipv", nang=64, nrad=48):
+    """Second derivatives for ONE ECP atom, [3, 3, nao_int, nao_int] (internal Cartesian AO order): "ipipv" = <d_i d_j a| U_C |b>,
+    "ipvip" = <d_i a| U_C |d_j b> (libcint's ``ECPscalar_ipiprinv`` / ``ECPscalar_iprinvip`` for the nucleus selected by
+    ``with_rinv_at_nucleus``; reference get_ecp_ipip, backend/ecp.py:1141-1340).  Same quadrature as ``ecp_scalar``."""
+    assert ip_type in ("ipipv", "ipvip")
+    nao = int(layout.ao_loc[-1])
+    V = np.zeros((3, 3, nao, nao))
+    r, wr = _radial(nrad)
+    ang, wang = _angular(nang)
+    C = np.asarray(coords_of_atom[atom], dtype=float)
+    by_l = {}
+    for l, power, zeta, coef in channels[atom]:
+        by_l.setdefault(l, []).append((power, zeta, coef))
+    ylm = {l: real_sph_harm(l, ang) for l in by_l if l >= 0}
+    ul = {l: _u(r, t) for l, t in by_l.items()}
+    for n in range(len(r)):
+        pts = C + r[n] * ang
+        ao = dft.eval_ao_cart(layout.packed, layout.ao_loc, pts, deriv=1)
+        hess = ao_second_derivatives(layout.packed, layout.ao_loc, pts) if ip_type == "ipipv" else None
+        for i in range(3):
+            for j in range(3):
+                bra, ket = (hess[i, j], ao[0]) if ip_type == "ipipv" else (ao[1 + i], ao[1 + j])
+                if -1 in by_l:
+                    V[i, j] += (wr[n] * r[n] ** 2 * ul[-1][n]) * (bra * wang) @ ket.T
+                for l, y in ylm.items():
+                    V[i, j] += (wr[n] * r[n] ** 2 * ul[l][n]) * ((bra * wang) @ y.T) @ ((ket * wang) @ y.T).T
+    return V
+
+
+def ecp_ipip_mol(layout, mol, atom, ip_type="ipipv", nang=64, nrad=48):
+    """[9, nao, nao] in the molecule's own AO basis, component 3 i + j (the layout of ``mol.intor("ECPscalar_ipiprinv")``)."""
+    from joltqc_amd.gto import ecp as gecp
+    V = ecp_ipip(layout, gecp.channels(mol), mol.atom_coords(), atom, ip_type, nang, nrad)
+    T = layout.transform_matrix()
+    return np.einsum("pi,xypq,qj->xyij", T, V, T).reshape(9, T.shape[1], T.shape[1])

@@ -13,6 +13,45 @@ import copy
 import numpy as np
 
 
+_BIG = 600       # matrices from this size on: the driver's OWN dense linear algebra (products, eigh) runs through torch on the GPU
+
+
+def _on_device(mats):
+    if max(max(m.shape) for m in mats) < _BIG:
+        return None
+    try:
+        import torch
+        return torch.device("cuda") if torch.cuda.is_available() else None
+    except ImportError:
+        return None
+
+
+def _mm(*mats):
+    """Product of dense NumPy matrices -> NumPy.  A 2 588-AO SCF spends more time in NumPy's products and eigh on the host than in the
+    J/K builds under test; where a GPU is present the stand-in's own linear algebra (NOT the closures under test, which still get and
+    return what PySCF would hand them) goes through torch in FP64.  Same arithmetic, NumPy in, NumPy out."""
+    dev = _on_device(mats)
+    if dev is None:
+        out = mats[0]
+        for m in mats[1:]:
+            out = out @ m
+        return out
+    import torch
+    out = torch.from_numpy(np.ascontiguousarray(mats[0])).to(dev)
+    for m in mats[1:]:
+        out = out @ torch.from_numpy(np.ascontiguousarray(m)).to(dev)
+    return out.cpu().numpy()
+
+
+def _eigh(A):
+    dev = _on_device((A,))
+    if dev is None:
+        return np.linalg.eigh(A)
+    import torch
+    e, c = torch.linalg.eigh(torch.from_numpy(np.ascontiguousarray(A)).to(dev))
+    return e.cpu().numpy(), c.cpu().numpy()
+
+
 def _strict(x):
     """What PySCF's NumPy code does with a potential: ``numpy.asarray`` (TypeError on a CUDA tensor)."""
     if hasattr(x, "is_cuda") and x.is_cuda:
@@ -155,26 +194,26 @@ class RHF:
         the orbitals the density was made of, divided by sqrt(its size), below conv_tol_grad (default sqrt(conv_tol))."""
         if c is None:
             return False
-        g = 2.0 * c[:, :nocc].T @ F @ c[:, nocc:]
+        g = 2.0 * _mm(c[:, :nocc].T, F, c[:, nocc:])
         self.norm_gorb = float(np.linalg.norm(g)) / np.sqrt(g.size)
         tol_g = np.sqrt(self.conv_tol) if self.conv_tol_grad is None else self.conv_tol_grad
         return abs(e_tot - e_last) < self.conv_tol and self.norm_gorb < tol_g
 
     def kernel(self, dm0=None):
         S, h = np.asarray(self._ovlp), np.asarray(self._hcore)
-        s, U = np.linalg.eigh(S)
+        s, U = _eigh(S)
         X = U[:, s > 1e-10] / np.sqrt(s[s > 1e-10])
         nocc = self.mol.nelectron // 2
         enuc = self.mol.energy_nuc()
 
         def solve(F):
-            e, c = np.linalg.eigh(X.T @ F @ X)
-            return e, X @ c
+            e, c = _eigh(_mm(X.T, F, X))
+            return e, _mm(X, c)
 
         c_cur = None                            # orbitals the current density was made of (none for a guess density)
         if dm0 is None:
             _, c_cur = solve(h)
-            dm = 2.0 * c_cur[:, :nocc] @ c_cur[:, :nocc].T
+            dm = 2.0 * _mm(c_cur[:, :nocc], c_cur[:, :nocc].T)
         else:
             dm = np.asarray(dm0)
         dm_last, vhf_last = None, None
@@ -186,7 +225,8 @@ class RHF:
             F = h + vhf
             e_tot = 0.5 * float(np.einsum("ij,ji->", dm, h + F)) + enuc
             done = self._converged(e_tot, e_last, F, c_cur, nocc)
-            err = X.T @ (F @ dm @ S - S @ dm @ F) @ X
+            fds = _mm(F, dm, S)
+            err = _mm(X.T, fds - fds.T, X)                      # F D S - S D F (F, D, S symmetric)
             focks.append(F)
             errs.append(err)
             focks, errs = focks[-self.diis_space:], errs[-self.diis_space:]
@@ -211,7 +251,7 @@ class RHF:
                 break
             self.mo_energy, self.mo_coeff = solve(F)
             c_cur = self.mo_coeff
-            dm = 2.0 * c_cur[:, :nocc] @ c_cur[:, :nocc].T
+            dm = 2.0 * _mm(c_cur[:, :nocc], c_cur[:, :nocc].T)
             e_last = e_tot
         # final energy with the converged density
         vhf = self._np(self.get_veff(self.mol, dm, dm_last=dm_last, vhf_last=vhf_last, hermi=1))
@@ -327,13 +367,13 @@ class RKS(RHF):
 
     def kernel(self, dm0=None):
         S, h = np.asarray(self._ovlp), np.asarray(self._hcore)
-        s, U = np.linalg.eigh(S)
+        s, U = _eigh(S)
         X = U[:, s > 1e-10] / np.sqrt(s[s > 1e-10])
         nocc = self.mol.nelectron // 2
         enuc = self.mol.energy_nuc()
-        _, c = np.linalg.eigh(X.T @ h @ X)
-        c = X @ c
-        dm = 2.0 * c[:, :nocc] @ c[:, :nocc].T if dm0 is None else np.asarray(dm0)
+        _, c = _eigh(_mm(X.T, h, X))
+        c = _mm(X, c)
+        dm = 2.0 * _mm(c[:, :nocc], c[:, :nocc].T) if dm0 is None else np.asarray(dm0)
         c_cur = c if dm0 is None else None
         dm_last, v_last, e_last = 0, 0, 0.0
         errs, focks = [], []
@@ -347,7 +387,8 @@ class RKS(RHF):
             if self._converged(e_tot, e_last, F, c_cur, nocc):
                 self.converged = True
                 break
-            err = X.T @ (F @ dm @ S - S @ dm @ F) @ X
+            fds = _mm(F, dm, S)
+            err = _mm(X.T, fds - fds.T, X)                      # F D S - S D F (F, D, S symmetric)
             focks.append(F); errs.append(err)
             focks, errs = focks[-self.diis_space:], errs[-self.diis_space:]
             if len(errs) > 1:
@@ -362,10 +403,10 @@ class RKS(RHF):
                     F = sum(wi * Fi for wi, Fi in zip(w, focks))
                 except np.linalg.LinAlgError:
                     pass
-            e, cc = np.linalg.eigh(X.T @ F @ X)
-            self.mo_energy, self.mo_coeff = e, X @ cc
+            e, cc = _eigh(_mm(X.T, F, X))
+            self.mo_energy, self.mo_coeff = e, _mm(X, cc)
             c_cur = self.mo_coeff
-            dm = 2.0 * c_cur[:, :nocc] @ c_cur[:, :nocc].T
+            dm = 2.0 * _mm(c_cur[:, :nocc], c_cur[:, :nocc].T)
             e_last = e_tot
         self.e_tot = e_tot
         return e_tot

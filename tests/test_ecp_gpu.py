@@ -84,6 +84,37 @@ def test_get_ecp_ip_against_the_oracle(kind, cart):
         becp.get_ecp_ip(mol, ip_type="ipipv")
 
 
+@pytest.mark.parametrize("cart", [False, True])
+@pytest.mark.parametrize("ip_type", ["ipipv", "ipvip"])
+def test_get_ecp_ipip_against_the_oracle(ip_type, cart):
+    """Second derivatives (reference get_ecp_ipip, backend/ecp.py:1141-1340; its tests: test_ecp_small.py:145-190, the sum over ECP atoms
+    against libcint's ECPscalar_ipipnuc / ECPscalar_ipnucip): [n_ecp, 9, nao, nao] from the value kernel on l +- 2 / l +- 1 auxiliary
+    shells (the g function of the reference's basis becomes an i shell: the kernel's l <= 6 instantiation), against the oracle's
+    quadrature with analytic AO second derivatives."""
+    from joltqc_amd.backend import ecp as becp
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import ecp as oecp
+    mol = na2(ECP_TYPE2, cart=cart)
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    got = becp.get_ecp_ipip(mol, ip_type=ip_type).cpu().numpy()
+    assert got.shape == (2, 9, mol.nao, mol.nao)
+    # (the oracle's AO Hessians make "ipipv" the slow leg: both ECP atoms in the Cartesian basis, one in the spherical one)
+    for n, atom in enumerate((0, 1) if (cart or ip_type == "ipvip") else (1,)):
+        n = atom
+        ref = oecp.ecp_ipip_mol(lay, mol, atom, ip_type, nang=32, nrad=32)
+        scale = np.abs(ref).max()
+        assert np.abs(got[n] - ref).max() < 1e-8 * scale, (atom, np.abs(got[n] - ref).max() / scale)
+    g9 = got.reshape(2, 3, 3, mol.nao, mol.nao)
+    if ip_type == "ipipv":
+        assert np.abs(g9 - g9.transpose(0, 2, 1, 3, 4)).max() < 1e-12 * np.abs(g9).max()
+    else:
+        assert np.abs(g9 - g9.transpose(0, 2, 1, 4, 3)).max() < 1e-12 * np.abs(g9).max()
+    one = becp.get_ecp_ipip(mol, ip_type=ip_type, ecp_atoms=[1]).cpu().numpy()
+    assert one.shape == (1, 9, mol.nao, mol.nao) and np.abs(one[0] - got[1]).max() < 1e-13 * np.abs(got[1]).max()
+    with pytest.raises(ValueError):                          # (the reference's own argument check, ecp.py:1158-1161)
+        becp.get_ecp_ipip(mol, ip_type="ip")
+
+
 def test_ecp_force_term_against_finite_differences():
     """d/dR tr(D h_ECP) at fixed D from the first-derivative blocks (translational invariance for the ECP centre itself)
     against central differences of the device's own value integrals, every atom and direction of a bent three-atom molecule

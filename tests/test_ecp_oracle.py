@@ -136,3 +136,46 @@ def test_oracle_first_derivative_against_finite_differences():
         fd = (vs[0] - vs[1]) / (2 * h)
         blk = np.ix_(on1, ~on1)
         assert np.abs(fd[blk] + ip[x][blk]).max() < 1e-7 * max(np.abs(ip[x][blk]).max(), 1e-3), x
+
+
+def test_oracle_second_derivatives_against_finite_differences():
+    """oracle.ecp.ao_second_derivatives against central differences of the AO gradients, and oracle.ecp.ecp_ipip against central
+    differences of ecp_ip when the shells of the other atom move: d/dA_j <d_i a|U_C|b> = -<d_i d_j a|U_C|b> for a on the moved atom
+    and b on the fixed one, = -<d_i a|U_C|d_j b> for a fixed and b moved."""
+    import copy
+    from joltqc_amd.gto import ecp as gecp
+    from joltqc_amd.pyscf.basis import BasisLayout
+    from oracle import dft as odft
+    from oracle import ecp as oecp
+    mol = na2(ECP_TYPE2, cart=True)
+    lay = BasisLayout.from_mol(mol, alignment=1)
+    pts = np.random.default_rng(3).normal(size=(40, 3)) * 1.5
+    hess = oecp.ao_second_derivatives(lay.packed, lay.ao_loc, pts)
+    h = 1e-5
+    for j in range(3):
+        d = np.zeros(3)
+        d[j] = h
+        fd = (odft.eval_ao_cart(lay.packed, lay.ao_loc, pts + d, deriv=1)[1:] - odft.eval_ao_cart(lay.packed, lay.ao_loc, pts - d, deriv=1)[1:]) / (2 * h)
+        assert np.abs(fd - hess[:, j]).max() < 1e-8 * np.abs(hess).max(), j
+    assert np.abs(hess - hess.transpose(1, 0, 2, 3)).max() == 0
+
+    # (the quadrature grid sits on the fixed ECP centre, so the identity holds at any grid size: a coarse one keeps this fast)
+    ch = {0: gecp.channels(mol)[0]}
+    xyz = mol.atom_coords()
+    ipipv = oecp.ecp_ipip(lay, ch, xyz, 0, "ipipv", nang=16, nrad=16)
+    ipvip = oecp.ecp_ipip(lay, ch, xyz, 0, "ipvip", nang=16, nrad=16)
+    assert np.abs(ipvip - ipvip.transpose(1, 0, 3, 2)).max() < 1e-12 * np.abs(ipvip).max()
+    on1 = np.repeat(np.asarray(lay.atom_of) == 1, np.diff(lay.ao_loc))
+    h = 1e-4
+    for j in range(3):
+        vs = []
+        for sgn in (1, -1):
+            l2 = copy.copy(lay)
+            l2.packed = lay.packed.copy()
+            l2.packed[np.asarray(lay.atom_of) == 1, j] += sgn * h
+            vs.append(oecp.ecp_ip(l2, ch, xyz, 0, nang=16, nrad=16))
+        fd = (vs[0] - vs[1]) / (2 * h)                            # [3 (i), nao, nao]
+        moved_bra, moved_ket = np.ix_(on1, ~on1), np.ix_(~on1, on1)
+        for i in range(3):
+            assert np.abs(fd[i][moved_bra] + ipipv[i, j][moved_bra]).max() < 1e-6 * max(np.abs(ipipv[i, j][moved_bra]).max(), 1e-3), (i, j)
+            assert np.abs(fd[i][moved_ket] + ipvip[i, j][moved_ket]).max() < 1e-6 * max(np.abs(ipvip[i, j][moved_ket]).max(), 1e-3), (i, j)
