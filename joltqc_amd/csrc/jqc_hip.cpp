@@ -851,8 +851,8 @@ static int grad_quartets_per_pass(int li, int lj, int lk, int ll)
     const int qbytes = (3 * (gsz + 4 * gsb) + 2 * nrg + nf(lk) * nf(ll) + 9) * 8;
     auto gcap = [&](int budget) { const int g = budget / qbytes; return g < 256 / t ? (g < 1 ? 1 : g) : 256 / t; };
     static const bool two_wg_off = getenv("JQC_EXTRA_DEFS") && strstr(getenv("JQC_EXTRA_DEFS"), "-DGRAD_TWO_WG=0");
-    const bool two_wg = !two_wg_off && nf(lk) * nf(ll) <= 18 && 4 * gcap(78 * 1024) >= 3 * gcap(150 * 1024);
-    return two_wg ? gcap(78 * 1024) : gcap(150 * 1024);
+    const bool two_wg = !two_wg_off && nf(lk) * nf(ll) <= 18 && 4 * gcap(72 * 1024) >= 3 * gcap(150 * 1024);
+    return two_wg ? gcap(72 * 1024) : gcap(150 * 1024);
 }
 
 int jqc_gen_jk_grad_kernel(int li, int lj, int lk, int ll, int rys_lr, int compile_only)
@@ -861,15 +861,14 @@ int jqc_gen_jk_grad_kernel(int li, int lj, int lk, int ll, int rys_lr, int compi
     if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
     // Which form (jk_grad.hip): the cooperative one (GRAD_COOP) where it measured faster on the 112-atom def2-TZVPP gradient
-    // (39 of the 65 s..f classes, profiles/r03_grad_forms_per_class_112atoms_tzvpp.txt: everything with a ket block of >= 18
-    // components and most (.. | dp), (.. | pp), (.. | ds) classes with a d or f bra), the one-quartet-per-lane form for the rest
-    // (small ket blocks: three barriers per root buy nothing).  g classes (not in that workload): by the size of the ket block.
+    // (32 of the 65 s..f classes, profiles/r05_grad_forms_per_class_112atoms_tzvpp.txt -- round 5, after the one-quartet-per-lane
+    // form got its LDS per-atom table, block-wise density reads and the W form: everything from 324 integrals with a p, d or f
+    // ket pair, and (dp|pp)), the one-quartet-per-lane form for the rest.  g classes (not in that workload): by the size of the ket block.
     // JQC_GRAD_COOP=0 / 1 forces one form on every class (A/B).
     static const int coop_env = getenv("JQC_GRAD_COOP") ? atoi(getenv("JQC_GRAD_COOP")) : -1;
-    static const char* const kCoopWins[] = {"1000", "2022", "2111", "2120", "2121", "2122", "2211", "2220", "2221", "2222",
-        "3021", "3022", "3031", "3032", "3111", "3120", "3121", "3122", "3130", "3131", "3132", "3133", "3211", "3220",
-        "3221", "3222", "3230", "3231", "3232", "3233", "3310", "3311", "3320", "3321", "3322", "3330", "3331", "3332",
-        "3333"};
+    static const char* const kCoopWins[] = {"2111", "2121", "2122", "2211", "2221", "2222", "3022", "3031", "3032", "3111", "3121", "3122",
+        "3130", "3131", "3132", "3133", "3211", "3220", "3221", "3222", "3230", "3231", "3232", "3233", "3311", "3320", "3321", "3322",
+        "3330", "3331", "3332", "3333"};
     int coop = coop_env;
     if (coop < 0) {
         if (li <= 3) {

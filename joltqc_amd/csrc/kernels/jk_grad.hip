@@ -25,9 +25,24 @@ constexpr int DI = LI + 2, DJ = LJ + 2, DK = LK + 2, DL = LL + 1;
 constexpr int SL = 1, SK = DL, SJ = DK * DL, SI = DJ * DK * DL;
 constexpr int GSZ = DI * SI;
 #ifndef GRAD_UNROLL
-#define GRAD_UNROLL (NINT <= 108)
+#define GRAD_UNROLL 1    // component loops of the one-quartet-per-lane form carry "#pragma unroll" (compile-time record offsets; the compiler
+                         // gives up by itself on the largest classes); 0: "nounroll" (A/B)
 #endif
-constexpr bool P_ARRAY = NINT <= 1296;               // effective density as one value per component (else from its six sub-blocks)
+#define NF_PP(l) (((l) + 1) * ((l) + 2) / 2)
+#define NINT_PP (NF_PP(LI) * NF_PP(LJ) * NF_PP(LK) * NF_PP(LL))      // NINT for the preprocessor
+#ifndef GRAD_WFORM
+#define GRAD_WFORM (NINT_PP <= 400)   // one-quartet-per-lane form: the W form of the component loop (below) up to 400 integrals -- measured per class
+                                      // on the 112-atom def2-TZVPP gradient (profiles/r05_grad_forms_per_class_112atoms_tzvpp.txt): 1.1-2.4x
+                                      // faster from 27 to 360 integrals ((fp|ps) 610 -> 253 ms), slower from 540 on (its arrays spill more)
+#endif
+#ifndef GRAD_PMAX
+#define GRAD_PMAX 1296
+#endif
+#ifndef GRAD_ABL
+#define GRAD_ABL 0   // timing-only ablations (WRONG results; tools/grad_ab.py): 1 = no global atomics, 2 = no density gathers (P = 1),
+                     // 4 = one primitive combination per quartet; cooperative form: 8 / 16 / 32 = without phase B / A2 / A1
+#endif
+constexpr bool P_ARRAY = NINT <= GRAD_PMAX;               // effective density as one value per component (else from its six sub-blocks)
 constexpr int NS_MAX = 2;                            // spin densities (n_dm <= 2)
 #if GRAD_UNROLL
 #define GUNROLL _Pragma("unroll")
@@ -62,6 +77,9 @@ __device__ __forceinline__ void rys_roots_g(real x, real theta, real omega, cons
     const real u = (x - real(2.5) * it) * real(0.8) - real(1);
     const real u2 = u + u;
     const real* __restrict__ c = cheb + it * (NRG * NCOEF * 2);
+#ifdef GRAD_RYS_NOUNROLL
+#pragma nounroll
+#endif
     for (int i = 0; i < NRG; i++, c += NCOEF * 2) {
         real br1 = 0, br2 = 0, bw1 = 0, bw2 = 0;
 #pragma unroll
@@ -130,8 +148,20 @@ __device__ __forceinline__ void derivative_records(const real* __restrict__ g, c
                 }
 }
 
+// Per-atom accumulation of the one-quartet-per-lane form: a table of the first LDS_ATOMS atoms in LDS (ds_add_f64), flushed once per
+// workgroup; twelve GLOBAL atomics per quartet were 80 % of the (ps|ss) kernel's time and 54 % of (ds|ps)'s
+// (profiles/r05_grad_one_lane_ablations.txt).  Atoms beyond the table go to global memory directly.
+#ifndef LDS_ATOMS
+#define LDS_ATOMS 1024
+#endif
+__device__ __forceinline__ void atom_add(double* __restrict__ table, double* __restrict__ grad, const int atom, const int x, const double v)
+{
+    if (atom < LDS_ATOMS) atomicAdd(&table[atom * 3 + x], v);
+    else atomic_add_f64(grad + atom * 3 + x, v);
+}
+
 __device__ __forceinline__ void quartet_grad(const int nao, const real* __restrict__ basis, const real* __restrict__ dm,
-                                             const int n_dm, double* __restrict__ grad, const int* __restrict__ shell_atom,
+                                             const int n_dm, double* __restrict__ table, double* __restrict__ grad, const int* __restrict__ shell_atom,
                                              const real jfac, const real kfac, const real omega, const ushort4 sq,
                                              const real* __restrict__ rys_cheb, const real* __restrict__ rys_large)
 {
@@ -154,17 +184,72 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
     const real rkl[3] = {bl[0] - rkx, bl[1] - rky, bl[2] - rkz};
     const real rr_ij = rij[0] * rij[0] + rij[1] * rij[1] + rij[2] * rij[2];
     const real rr_kl = rkl[0] * rkl[0] + rkl[1] * rkl[1] + rkl[2] * rkl[2];
+#if GRAD_ABL & 4
+    const int npi = 1, npj = 1, npk = 1, npl = 1;
+#else
     const int npi = (int)bi[10], npj = (int)bj[10], npk = (int)bk[10], npl = (int)bl[10];
+#endif
     const int i0 = (int)bi[3], j0 = (int)bj[3], k0 = (int)bk[3], l0 = (int)bl[3];
 
     // effective two-particle density of the quartet (independent of the primitives): as one value per component where that
     // array is small, otherwise from the six density sub-blocks (total density for J, one set per spin for K)
+    // The six density sub-blocks of the quartet are read ONCE (NFI*NFJ + NFK*NFL + n_dm (NFI + NFJ)(NFK + NFL) gathers; reading them
+    // per component cost six gathers per integral: 90 % of the (fd|ps) kernel's time, profiles/r05_grad_one_lane_ablations.txt), then
+    // P is formed from them: as one value per component where that array is small, otherwise on the fly in the component loop.
     const size_t nao2 = (size_t)nao * nao;
     real P[P_ARRAY ? NINT : 1];
-    real tij[P_ARRAY ? 1 : NFI * NFJ], tkl[P_ARRAY ? 1 : NFK * NFL];
-    real sik[P_ARRAY ? 1 : NS_MAX * NFI * NFK], sil[P_ARRAY ? 1 : NS_MAX * NFI * NFL];
-    real sjk[P_ARRAY ? 1 : NS_MAX * NFJ * NFK], sjl[P_ARRAY ? 1 : NS_MAX * NFJ * NFL];
+    real tij[NFI * NFJ], tkl[NFK * NFL];
+    real sik[NS_MAX][NFI * NFK], sil[NS_MAX][NFI * NFL], sjk[NS_MAX][NFJ * NFK], sjl[NS_MAX][NFJ * NFL];
     const real kscale = kfac * n_dm;
+    {
+        const bool two = n_dm > 1 && !(GRAD_ABL & 2);
+        const real* __restrict__ D0 = dm;
+        const real* __restrict__ D1 = dm + (two ? nao2 : 0);
+        const real on0 = (GRAD_ABL & 2) ? real(0) : real(1);
+        GUNROLL
+        for (int i = 0; i < NFI; i++) {
+            GUNROLL
+            for (int j = 0; j < NFJ; j++) {
+                const size_t a = (size_t)(i0 + i) * nao + j0 + j;
+                tij[i * NFJ + j] = real(4) * jfac * (on0 * D0[a] + (two ? D1[a] : real(0)));
+            }
+            GUNROLL
+            for (int k = 0; k < NFK; k++) {
+                const size_t a = (size_t)(i0 + i) * nao + k0 + k;
+                sik[0][i * NFK + k] = kscale * on0 * D0[a];
+                sik[1][i * NFK + k] = two ? kscale * D1[a] : real(0);
+            }
+            GUNROLL
+            for (int l = 0; l < NFL; l++) {
+                const size_t a = (size_t)(i0 + i) * nao + l0 + l;
+                sil[0][i * NFL + l] = kscale * on0 * D0[a];
+                sil[1][i * NFL + l] = two ? kscale * D1[a] : real(0);
+            }
+        }
+        GUNROLL
+        for (int j = 0; j < NFJ; j++) {
+            GUNROLL
+            for (int k = 0; k < NFK; k++) {
+                const size_t a = (size_t)(j0 + j) * nao + k0 + k;
+                sjk[0][j * NFK + k] = on0 * D0[a];
+                sjk[1][j * NFK + k] = two ? D1[a] : real(0);
+            }
+            GUNROLL
+            for (int l = 0; l < NFL; l++) {
+                const size_t a = (size_t)(j0 + j) * nao + l0 + l;
+                sjl[0][j * NFL + l] = on0 * D0[a];
+                sjl[1][j * NFL + l] = two ? D1[a] : real(0);
+            }
+        }
+        GUNROLL
+        for (int k = 0; k < NFK; k++) {
+            GUNROLL
+            for (int l = 0; l < NFL; l++) {
+                const size_t a = (size_t)(k0 + k) * nao + l0 + l;
+                tkl[k * NFL + l] = on0 * D0[a] + (two ? D1[a] : real(0));
+            }
+        }
+    }
     if (P_ARRAY) {
         GUNROLL
         for (int i = 0; i < NFI; i++)
@@ -174,39 +259,14 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
         for (int k = 0; k < NFK; k++)
         GUNROLL
         for (int l = 0; l < NFL; l++) {
-            real dij = 0, dkl = 0, kk = 0;
-            for (int s = 0; s < n_dm; s++) {
-                const real* __restrict__ D = dm + s * nao2;
-                dij += D[(size_t)(i0 + i) * nao + j0 + j];
-                dkl += D[(size_t)(k0 + k) * nao + l0 + l];
-                kk += D[(size_t)(i0 + i) * nao + k0 + k] * D[(size_t)(j0 + j) * nao + l0 + l] +
-                      D[(size_t)(i0 + i) * nao + l0 + l] * D[(size_t)(j0 + j) * nao + k0 + k];
-            }
-            P[((i * NFJ + j) * NFK + k) * NFL + l] = real(4) * jfac * dij * dkl - kscale * kk;
-        }
-    } else {
-        for (int i = 0; i < NFI; i++)
-            for (int j = 0; j < NFJ; j++) {
-                real v = 0;
-                for (int s = 0; s < n_dm; s++) v += dm[s * nao2 + (size_t)(i0 + i) * nao + j0 + j];
-                tij[i * NFJ + j] = real(4) * jfac * v;
-            }
-        for (int k = 0; k < NFK; k++)
-            for (int l = 0; l < NFL; l++) {
-                real v = 0;
-                for (int s = 0; s < n_dm; s++) v += dm[s * nao2 + (size_t)(k0 + k) * nao + l0 + l];
-                tkl[k * NFL + l] = v;
-            }
-        for (int s = 0; s < n_dm; s++) {
-            const real* __restrict__ D = dm + s * nao2;
-            for (int i = 0; i < NFI; i++) {
-                for (int k = 0; k < NFK; k++) sik[(s * NFI + i) * NFK + k] = kscale * D[(size_t)(i0 + i) * nao + k0 + k];
-                for (int l = 0; l < NFL; l++) sil[(s * NFI + i) * NFL + l] = kscale * D[(size_t)(i0 + i) * nao + l0 + l];
-            }
-            for (int j = 0; j < NFJ; j++) {
-                for (int k = 0; k < NFK; k++) sjk[(s * NFJ + j) * NFK + k] = D[(size_t)(j0 + j) * nao + k0 + k];
-                for (int l = 0; l < NFL; l++) sjl[(s * NFJ + j) * NFL + l] = D[(size_t)(j0 + j) * nao + l0 + l];
-            }
+            real p = tij[i * NFJ + j] * tkl[k * NFL + l];
+#pragma unroll
+            for (int s = 0; s < NS_MAX; s++)
+                p -= sik[s][i * NFK + k] * sjl[s][j * NFL + l] + sil[s][i * NFL + l] * sjk[s][j * NFK + k];
+#if GRAD_ABL & 2
+            p = real(1);
+#endif
+            P[((i * NFJ + j) * NFK + k) * NFL + l] = p;
         }
     }
 
@@ -244,6 +304,65 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
                 const real b10 = real(0.5) * inv_aij * (real(1) - rt_aij);
                 const real b01 = real(0.5) * inv_akl * (real(1) - rt_akl);
                 const real b00 = real(0.5) * rt_aa;
+#if GRAD_WFORM
+                // W form: the nine sums are  sum_b dX_c(b) W_x(b)  with  W_x(b) = sum over the components whose x index tuple is b of
+                // P Y Z  (and the same for y, z): the component loop touches the three undifferentiated 1-D values and three
+                // accumulators (6 flops, 3 + 1 loads) instead of three 32-byte records and nine sums (13 flops, 12 + 1 loads); the
+                // derivative values are used once per index tuple in the epilogue.  The lane's arrays live in scratch for all but the
+                // smallest classes: the traffic of the component loop is what this form cuts.
+                real v[3][GSB], d[3][GSB][3], W[3][GSB];
+                {
+                    real g[GSZ];
+#pragma unroll
+                    for (int ax = 0; ax < 3; ax++) {
+                        axis_integrals_g(ax == 0 ? ckcl : ax == 1 ? gy0 : wt, rpa[ax] - rt_aij * rpq[ax], rqc[ax] + rt_akl * rpq[ax], b10, b01, b00,
+                                         rij[ax], rkl[ax], g);
+                        for (int i = 0; i <= LI; i++)
+                            for (int j = 0; j <= LJ; j++)
+                                for (int k = 0; k <= LK; k++)
+                                    for (int l = 0; l <= LL; l++) {
+                                        const int e = i * SI + j * SJ + k * SK + l;
+                                        const int b = i * BI + j * BJ + k * BK + l;
+                                        v[ax][b] = g[e];
+                                        d[ax][b][0] = ai2 * g[e + SI] - (i ? i * g[e - SI] : real(0));
+                                        d[ax][b][1] = aj2 * g[e + SJ] - (j ? j * g[e - SJ] : real(0));
+                                        d[ax][b][2] = ak2 * g[e + SK] - (k ? k * g[e - SK] : real(0));
+                                        W[ax][b] = 0;
+                                    }
+                    }
+                }
+                GUNROLL
+                for (int i = 0; i < NFI; i++)
+                GUNROLL
+                for (int j = 0; j < NFJ; j++)
+                GUNROLL
+                for (int k = 0; k < NFK; k++)
+                GUNROLL
+                for (int l = 0; l < NFL; l++) {
+                    const int bx = TI.x[i] * BI + TJ.x[j] * BJ + TK.x[k] * BK + TL.x[l];
+                    const int by = TI.y[i] * BI + TJ.y[j] * BJ + TK.y[k] * BK + TL.y[l];
+                    const int bz = TI.z[i] * BI + TJ.z[j] * BJ + TK.z[k] * BK + TL.z[l];
+                    real p;
+                    if (P_ARRAY) p = P[((i * NFJ + j) * NFK + k) * NFL + l];
+                    else {
+                        p = tij[i * NFJ + j] * tkl[k * NFL + l];
+#pragma unroll
+                        for (int s = 0; s < NS_MAX; s++)
+                            p -= sik[s][i * NFK + k] * sjl[s][j * NFL + l] + sil[s][i * NFL + l] * sjk[s][j * NFK + k];
+                    }
+                    const real X = v[0][bx], Y = v[1][by], Z = v[2][bz];
+                    W[0][bx] += p * (Y * Z);
+                    W[1][by] += p * (X * Z);
+                    W[2][bz] += p * (X * Y);
+                }
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++)
+                    GUNROLL
+                    for (int b = 0; b < GSB; b++) {
+                        const real w = W[ax][b];
+                        gA[ax] += w * d[ax][b][0]; gB[ax] += w * d[ax][b][1]; gC[ax] += w * d[ax][b][2];
+                    }
+#else
                 // per axis: the 1-D integrals over the class's own index ranges together with their three centre derivatives,
                 // q[idx][0..3] = {g, dg/dA, dg/dB, dg/dC} (one 32-byte record per index: three wide loads per component below)
                 real qx[GSB][4], qy[GSB][4], qz[GSB][4];
@@ -271,9 +390,9 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
                     if (P_ARRAY) p = P[((i * NFJ + j) * NFK + k) * NFL + l];
                     else {
                         p = tij[i * NFJ + j] * tkl[k * NFL + l];
-                        for (int s = 0; s < n_dm; s++)
-                            p -= sik[(s * NFI + i) * NFK + k] * sjl[(s * NFJ + j) * NFL + l] +
-                                 sil[(s * NFI + i) * NFL + l] * sjk[(s * NFJ + j) * NFK + k];
+#pragma unroll
+                        for (int s = 0; s < NS_MAX; s++)
+                            p -= sik[s][i * NFK + k] * sjl[s][j * NFL + l] + sil[s][i * NFL + l] * sjk[s][j * NFK + k];
                     }
                     const real X = qx[bx][0], Y = qy[by][0], Z = qz[bz][0];
                     const real pyz = p * Y * Z, pxz = p * X * Z, pxy = p * X * Y;
@@ -281,15 +400,19 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
                     gA[1] += pxz * qy[by][1]; gB[1] += pxz * qy[by][2]; gC[1] += pxz * qy[by][3];
                     gA[2] += pxy * qz[bz][1]; gB[2] += pxy * qz[bz][2]; gC[2] += pxy * qz[bz][3];
                 }
+#endif  // GRAD_WFORM
             }
         }
     }
+#if GRAD_ABL & 1
+    if (gA[0] != real(1.2345e300)) return;
+#endif
 #pragma unroll
     for (int x = 0; x < 3; x++) {
-        atomic_add_f64(grad + atom_i * 3 + x, (double)gA[x]);
-        atomic_add_f64(grad + atom_j * 3 + x, (double)gB[x]);
-        atomic_add_f64(grad + atom_k * 3 + x, (double)gC[x]);
-        atomic_add_f64(grad + atom_l * 3 + x, -(double)(gA[x] + gB[x] + gC[x]));
+        atom_add(table, grad, atom_i, x, (double)gA[x]);
+        atom_add(table, grad, atom_j, x, (double)gB[x]);
+        atom_add(table, grad, atom_k, x, (double)gC[x]);
+        atom_add(table, grad, atom_l, x, -(double)(gA[x] + gB[x] + gC[x]));
     }
 }
 
@@ -314,9 +437,12 @@ __device__ __forceinline__ void quartet_grad(const int nao, const real* __restri
 //   per quartet:  the nine sums of its T lanes are added in LDS, twelve global atomics per quartet instead of per lane.
 // Quartets of one pass may have different primitive counts: the combination loop runs to the largest count of the pass.
 constexpr int T = NFI * NFJ;
+#ifndef LDS_ATOMS_COOP
+#define LDS_ATOMS_COOP 256
+#endif
 // quartets per pass: as many as the 256 lanes hold, capped by the LDS their 1-D arrays take.  Two workgroups per CU (78 KB each,
 // two waves per SIMD: one workgroup's barriers and thin phases hide behind the other's phase B) where that costs at most a
-// quarter of the lanes, otherwise one workgroup with up to 150 KB.  (The host launcher repeats this arithmetic: jqc_hip.cpp,
+// quarter of the lanes, otherwise one workgroup with up to 150 KB (+ 6 KB each for the per-atom table sGA below: 2 x 78 / 156 of 160 KB).  (The host launcher repeats this arithmetic: jqc_hip.cpp,
 // grad_quartets_per_pass.)
 constexpr int QBYTES = (3 * (GSZ + 4 * GSB) + 2 * NRG + NFK * NFL + 9) * 8;
 constexpr int gcap(int budget) { return budget / QBYTES < 256 / T ? (budget / QBYTES < 1 ? 1 : budget / QBYTES) : 256 / T; }
@@ -325,11 +451,11 @@ constexpr int gcap(int budget) { return budget / QBYTES < 256 / T ? (budget / QB
 #endif
 // (measured: the 256-register cap of two workgroups per CU pays up to a ket block of 18 components -- (fp|dp) 1 334 -> 967 ms --,
 //  larger ket blocks spill under it -- (fd|dd) 322 -> 504 ms -- and keep one workgroup with 512 registers per lane)
-constexpr bool TWO_WG = GRAD_TWO_WG && NFK * NFL <= 18 && 4 * gcap(78 * 1024) >= 3 * gcap(150 * 1024);
+constexpr bool TWO_WG = GRAD_TWO_WG && NFK * NFL <= 18 && 4 * gcap(72 * 1024) >= 3 * gcap(150 * 1024);
 // effective density of the lane's components held in registers for the whole pass: up to 18 components under the 256-register cap
 // of two workgroups per CU, up to 60 with one workgroup (512 registers)
 constexpr bool P_REGS = NFK * NFL <= (TWO_WG ? 18 : 60);
-constexpr int G = TWO_WG ? gcap(78 * 1024) : gcap(150 * 1024);
+constexpr int G = TWO_WG ? gcap(72 * 1024) : gcap(150 * 1024);
 #ifdef EXPECT_G     // (the generator passes its own evaluation of this arithmetic, jqc_hip.cpp:grad_quartets_per_pass)
 static_assert(EXPECT_G == G, "jqc_hip.cpp:grad_quartets_per_pass is out of sync with the constants of jk_grad.hip");
 #endif
@@ -437,6 +563,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     __shared__ real sRW[G][2 * NRG];
     __shared__ real sDkl[G][NFK * NFL];
     __shared__ double sAcc[G][9];
+    __shared__ double sGA[LDS_ATOMS_COOP * 3];     // per-atom sums of this workgroup (atoms below LDS_ATOMS_COOP), flushed once at the end
     __shared__ int s_ncomb;
     const int tid = threadIdx.x;
     const int slot = tid / T, lt = tid - slot * T;
@@ -449,6 +576,8 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     const real kscale = kfac * n_dm;
     // index bases of this lane's bra component pair inside the record arrays
     const int bx0 = TI.x[ci] * BI + TJ.x[cj] * BJ, by0 = TI.y[ci] * BI + TJ.y[cj] * BJ, bz0 = TI.z[ci] * BI + TJ.z[cj] * BJ;
+    const int ntab = (natm < LDS_ATOMS_COOP ? natm : LDS_ATOMS_COOP) * 3;
+    for (int n = tid; n < ntab; n += 256) sGA[n] = 0;      // (the first barrier of the pass loop orders this before any use)
 
     for (long base = (long)blockIdx.x * G; base < ntasks; base += (long)gridDim.x * G) {
         const long task = base + slot;
@@ -563,7 +692,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #define GRAD_A1_ROWS 1
 #endif
                 constexpr int NJOB = GRAD_A1_ROWS ? 3 * DI : 3;
-                if (act)
+                if (act && !(GRAD_ABL & 32))
                     for (int job = lt; job < NJOB; job += T) {
                         const int ax = GRAD_A1_ROWS ? job / DI : job, ie = GRAD_A1_ROWS ? job - ax * DI : 0;
                         const real t2 = sRW[sl][2 * ir], wt = sRW[sl][2 * ir + 1];
@@ -595,7 +724,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     }
                 __syncthreads();
                 // ---- A2: derivative records {g, dg/dA, dg/dB, dg/dC} of every index tuple, all lanes of the quartet
-                if (act)
+                if (act && !(GRAD_ABL & 16))
                     for (int n = lt; n < 3 * GSB; n += T) {
                         const int ax = n / GSB, b = n - ax * GSB;
                         const int i = b / BI, j = (b / BJ) % (LJ + 1), k = (b / BK) % (LK + 1), l = b % (LL + 1);
@@ -609,7 +738,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     }
                 __syncthreads();
                 // ---- B: this lane's bra component pair against every ket component
-                if (act) {
+                if (act && !(GRAD_ABL & 8)) {
                     const real (*__restrict__ qx)[4] = sQ[sl][0];
                     const real (*__restrict__ qy)[4] = sQ[sl][1];
                     const real (*__restrict__ qz)[4] = sQ[sl][2];
@@ -651,20 +780,46 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 const int c = n / 3, x = n - c * 3;
                 const double v = c < 3 ? sAcc[sl][c * 3 + x] : -(sAcc[sl][x] + sAcc[sl][3 + x] + sAcc[sl][6 + x]);
                 const int atom = c == 0 ? atom_i : c == 1 ? atom_j : c == 2 ? atom_k : atom_l;
-                atomic_add_f64(gout + atom * 3 + x, v);
+                if (atom < LDS_ATOMS_COOP) atomicAdd(&sGA[atom * 3 + x], v);
+                else atomic_add_f64(gout + atom * 3 + x, v);
             }
+    }
+    __syncthreads();
+    for (int n = tid; n < ntab; n += 256) {
+        const double v = sGA[n];
+        if (v != 0.0) atomic_add_f64(gout + n, v);
     }
 }
 #else
-extern "C" __global__ void __launch_bounds__(BLOCK)
+#ifndef GRAD_MINW
+#define GRAD_MINW 1      // workgroups per CU the register allocation aims at (A/B: tools/grad_ab.py)
+#endif
+extern "C" __global__ void __launch_bounds__(BLOCK, GRAD_MINW)
 KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm, const int n_dm, double* __restrict__ grad,
       const int* __restrict__ shell_atom, const int natm, const int nrep, const real jfac, const real kfac, const real omega,
       const ushort4* __restrict__ quartets, const unsigned* __restrict__ ntasks_ptr, const int qstride,
       const real* __restrict__ rys_cheb, const real* __restrict__ rys_large)
 {
+    __shared__ double sG[LDS_ATOMS * 3];
+    // Chebyshev table of the class's NRG roots in LDS (as the J/K kernels keep theirs, jk_tile.hip sRys): every lane reads the 28
+    // coefficients per root of ITS OWN x interval, 64 different cache lines per wave instruction when the table is in global memory
+    constexpr int RYS_TAB_G = (2 * NRG + 14) * NRG * NCOEF * 2;
+    constexpr bool RYS_LDS_G = RYS_TAB_G * (int)sizeof(real) <= 36 * 1024;          // up to six roots
+    __shared__ real sRysG[RYS_LDS_G ? RYS_TAB_G : 1];
+    if (RYS_LDS_G)
+        for (int n = threadIdx.x; n < RYS_TAB_G; n += blockDim.x) sRysG[n] = rys_cheb[n];
+    const real* cheb_tab = RYS_LDS_G ? sRysG : rys_cheb;
     const long ntasks = *ntasks_ptr;
     double* __restrict__ g = grad + (size_t)(blockIdx.x % nrep) * natm * 3;
+    const int ntab = (natm < LDS_ATOMS ? natm : LDS_ATOMS) * 3;
+    for (int n = threadIdx.x; n < ntab; n += blockDim.x) sG[n] = 0;
+    __syncthreads();
     for (long task = (long)blockIdx.x * blockDim.x + threadIdx.x; task < ntasks; task += (long)gridDim.x * blockDim.x)
-        quartet_grad(nao, basis, dm, n_dm, g, shell_atom, jfac, kfac, omega, quartets[task * qstride], rys_cheb, rys_large);
+        quartet_grad(nao, basis, dm, n_dm, sG, g, shell_atom, jfac, kfac, omega, quartets[task * qstride], cheb_tab, rys_large);
+    __syncthreads();
+    for (int n = threadIdx.x; n < ntab; n += blockDim.x) {
+        const double v = sG[n];
+        if (v != 0.0) atomic_add_f64(g + n, v);
+    }
 }
 #endif  // GRAD_COOP

@@ -36,7 +36,8 @@ def generate_jk_energy_per_atom(basis_layout, cutoff=1e-13, shard=None):
     log_cutoff = float(np.float32(math.log(cutoff)))
     state = {"pairs": {}, "queue": None, "stats": {}, "atom": None}
 
-    def jk_energy_per_atom(mol=None, dm=None, j_factor=1.0, k_factor=1.0, omega=None, hermi=1, verbose=None):
+    def jk_energy_per_atom(mol=None, dm=None, j_factor=1.0, k_factor=1.0, omega=None, hermi=1, verbose=None, _classes=None):
+        # (_classes: predicate on the angular class (li, lj, lk, ll) -- per-class timing tools only)
         assert hermi == 1, "the gradient kernels take symmetric densities"
         if omega is not None:
             assert omega >= 0.0, "short ranged J/K not supported"
@@ -64,7 +65,7 @@ def generate_jk_energy_per_atom(basis_layout, cutoff=1e-13, shard=None):
         if om not in state["pairs"]:
             state["pairs"][om] = _jk._PairTables(layout, om)
         pt = state["pairs"][om]
-        plans = _jk.build_screen_plan(layout, pt, log_cutoff, log_max_dm2, _jk.QUEUE_DEPTH, None, shard)
+        plans = _jk.build_screen_plan(layout, pt, log_cutoff, log_max_dm2, _jk.QUEUE_DEPTH, _classes, shard)
         qsize = max((p["total"] for p in plans), default=0)
         if plans and (state["queue"] is None or state["queue"].numel() < qsize * 4):
             state["queue"] = torch.empty(max(qsize, 1) * 4, dtype=torch.int16, device=dev)
