@@ -848,7 +848,8 @@ static int grad_quartets_per_pass(int li, int lj, int lk, int ll)
     const int t = nf(li) * nf(lj);
     const int gsz = (li + 2) * (lj + 2) * (lk + 2) * (ll + 1), gsb = (li + 1) * (lj + 1) * (lk + 1) * (ll + 1);
     const int nrg = (li + lj + lk + ll + 1) / 2 + 1;
-    const int qbytes = (3 * (gsz + 4 * gsb) + 2 * nrg + nf(lk) * nf(ll) + 9) * 8;
+    static const bool a1_map_off = getenv("JQC_EXTRA_DEFS") && strstr(getenv("JQC_EXTRA_DEFS"), "-DGRAD_A1_MAP=0");      // (A/B builds)
+    const int qbytes = (3 * (gsz + 4 * gsb) + 2 * nrg + nf(lk) * nf(ll) + 9 + (a1_map_off ? 0 : 24)) * 8;      // (+ NPAR: sPar)
     auto gcap = [&](int budget) { const int g = budget / qbytes; return g < 256 / t ? (g < 1 ? 1 : g) : 256 / t; };
     static const bool two_wg_off = getenv("JQC_EXTRA_DEFS") && strstr(getenv("JQC_EXTRA_DEFS"), "-DGRAD_TWO_WG=0");
     const bool two_wg = !two_wg_off && nf(lk) * nf(ll) <= 18 && 4 * gcap(72 * 1024) >= 3 * gcap(150 * 1024);

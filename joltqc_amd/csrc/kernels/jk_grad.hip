@@ -444,7 +444,11 @@ constexpr int T = NFI * NFJ;
 // two waves per SIMD: one workgroup's barriers and thin phases hide behind the other's phase B) where that costs at most a
 // quarter of the lanes, otherwise one workgroup with up to 150 KB (+ 6 KB each for the per-atom table sGA below: 2 x 78 / 156 of 160 KB).  (The host launcher repeats this arithmetic: jqc_hip.cpp,
 // grad_quartets_per_pass.)
-constexpr int QBYTES = (3 * (GSZ + 4 * GSB) + 2 * NRG + NFK * NFL + 9) * 8;
+#ifndef GRAD_A1_MAP
+#define GRAD_A1_MAP 1     // phase-A1 jobs dealt over the whole workgroup ordered by row (see A1 below); needs the quartets' parameters in LDS
+#endif
+constexpr int NPAR = 24;  // per-quartet parameters of the current primitive combination (sPar)
+constexpr int QBYTES = (3 * (GSZ + 4 * GSB) + 2 * NRG + NFK * NFL + 9 + (GRAD_A1_MAP ? NPAR : 0)) * 8;
 constexpr int gcap(int budget) { return budget / QBYTES < 256 / T ? (budget / QBYTES < 1 ? 1 : budget / QBYTES) : 256 / T; }
 #ifndef GRAD_TWO_WG
 #define GRAD_TWO_WG 1
@@ -461,8 +465,13 @@ static_assert(EXPECT_G == G, "jqc_hip.cpp:grad_quartets_per_pass is out of sync 
 #endif
 #if ((LK + 1) * (LK + 2) / 2) * ((LL + 1) * (LL + 2) / 2) <= 100
 #define BUNROLL _Pragma("unroll")          // ket loop of phase B with compile-time record offsets
+#ifndef GRAD_COOP_W
+#define GRAD_COOP_W 1
+#endif
 #else
 #define BUNROLL _Pragma("nounroll")
+#undef GRAD_COOP_W
+#define GRAD_COOP_W 0
 #endif
 static_assert(T <= 256, "a quartet must fit one workgroup");
 
@@ -563,6 +572,8 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     __shared__ real sRW[G][2 * NRG];
     __shared__ real sDkl[G][NFK * NFL];
     __shared__ double sAcc[G][9];
+    __shared__ real sPar[GRAD_A1_MAP ? G : 1][NPAR];
+    __shared__ int sRec[((3 * GSB + T - 1) / T) * T];
     __shared__ double sGA[LDS_ATOMS_COOP * 3];     // per-atom sums of this workgroup (atoms below LDS_ATOMS_COOP), flushed once at the end
     __shared__ int s_ncomb;
     const int tid = threadIdx.x;
@@ -576,14 +587,35 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     const real kscale = kfac * n_dm;
     // index bases of this lane's bra component pair inside the record arrays
     const int bx0 = TI.x[ci] * BI + TJ.x[cj] * BJ, by0 = TI.y[ci] * BI + TJ.y[cj] * BJ, bz0 = TI.z[ci] * BI + TJ.z[cj] * BJ;
+    // phase A2: the records lane lt of a quartet builds per root (n = lt + m T < 3 GSB), as offset into sExt[slot] | i << 20 | j << 23 |
+    // k << 26: a table in LDS shared by the quartets (in registers it cost the 256-register builds spills: (dp|dp) 677 -> 841 ms)
+    constexpr int NREC = (3 * GSB + T - 1) / T;
+    for (int n = tid; n < NREC * T; n += 256) {
+        const int ax = n / GSB, b = n - ax * GSB;
+        const int i = b / BI, j = (b / BJ) % (LJ + 1), k = (b / BK) % (LK + 1), l = b % (LL + 1);
+        sRec[n] = n < 3 * GSB ? ((ax * GSZ + i * SI + j * SJ + k * SK + l) | (i << 20) | (j << 23) | (k << 26)) : -1;
+    }
+#ifdef GRAD_STAMPS       // cycle counts of the phases of workgroup 0 (wave 0), printed at the end: tools/grad_ab.py with -DGRAD_STAMPS=1
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#define GSTAMP(n) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[n] += t_ - st_t; st_t = t_; }
+#else
+#define GSTAMP(n)
+#endif
     const int ntab = (natm < LDS_ATOMS_COOP ? natm : LDS_ATOMS_COOP) * 3;
     for (int n = tid; n < ntab; n += 256) sGA[n] = 0;      // (the first barrier of the pass loop orders this before any use)
 
+    // (the quartet of the NEXT pass is requested at the top of this one: one of the three dependent global-load levels of the pass
+    //  setup -- quartet -> shell rows -> density blocks -- is off the critical path)
+    ushort4 sq_next = {0, 0, 0, 0};
+    if (lane_on && (long)blockIdx.x * G + slot < ntasks) sq_next = quartets[((long)blockIdx.x * G + slot) * qstride];
     for (long base = (long)blockIdx.x * G; base < ntasks; base += (long)gridDim.x * G) {
         const long task = base + slot;
         bool on = lane_on && task < ntasks;
-        ushort4 sq = {0, 0, 0, 0};
-        if (on) sq = quartets[task * qstride];
+        const ushort4 sq = sq_next;
+        {
+            const long tn = task + (long)gridDim.x * G;
+            if (lane_on && tn < ntasks) sq_next = quartets[tn * qstride];
+        }
         const int ish = sq.x, jsh = sq.y, ksh = sq.z, lsh = sq.w;
         if (ksh > ish || ish < jsh || lsh > ksh) on = false;
         const int atom_i = shell_atom[ish], atom_j = shell_atom[jsh], atom_k = shell_atom[ksh], atom_l = shell_atom[lsh];
@@ -651,6 +683,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 }
         }
         real gA[3] = {0, 0, 0}, gB[3] = {0, 0, 0}, gC[3] = {0, 0, 0};
+        GSTAMP(0)
         for (int cmb = 0; cmb < ncomb_max; cmb++) {
             const bool act = cmb < ncomb;
             int c_ = act ? cmb : 0;
@@ -685,12 +718,59 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     sRW[sl][2 * r] = t2;
                     sRW[sl][2 * r + 1] = wt;
                 }
+#if GRAD_A1_MAP
+            if (lane_on && lt == 0) {
+                real* __restrict__ par = sPar[sl];
+                par[0] = act ? real(1) : real(0);
+                par[1] = ckcl; par[2] = gy0;
+                par[3] = rpa[0]; par[4] = rpa[1]; par[5] = rpa[2];
+                par[6] = rqc[0]; par[7] = rqc[1]; par[8] = rqc[2];
+                par[9] = rpq[0]; par[10] = rpq[1]; par[11] = rpq[2];
+                par[12] = rij[0]; par[13] = rij[1]; par[14] = rij[2];
+                par[15] = rkl[0]; par[16] = rkl[1]; par[17] = rkl[2];
+                par[18] = inv; par[19] = aij; par[20] = akl; par[21] = inv_aij; par[22] = inv_akl;
+            }
+#endif
             __syncthreads();
+            GSTAMP(1)
             for (int ir = 0; ir < NRG; ir++) {
                 // ---- A1: one lane per (quartet, axis, row i of the extended array)  (GRAD_A1_ROWS=0: per (quartet, axis), A/B)
 #ifndef GRAD_A1_ROWS
 #define GRAD_A1_ROWS 1
 #endif
+#if GRAD_A1_MAP && GRAD_A1_ROWS
+                // The row is a template argument behind a switch: lanes of one wave with different rows take the switch DI ways (that
+                // was half of the kernel's time, profiles/r05_grad_one_lane_ablations.txt).  The G * 3 * DI jobs of the pass are
+                // therefore dealt over ALL lanes of the workgroup ordered by row, a wave holding jobs of one row only, and a job reads
+                // its quartet's parameters from LDS (sPar) instead of the registers of that quartet's lanes.
+                constexpr int NJW = 3 * G, NJWP = (NJW + 63) / 64 * 64;      // (padded: a wave holds jobs of ONE row)
+                if (!(GRAD_ABL & 32))
+                for (int J = tid; J < DI * NJWP; J += 256) {
+                    const int ie = J / NJWP, r_ = J - ie * NJWP, q_ = r_ / 3, ax = r_ - 3 * q_;
+                    if (r_ >= NJW) continue;
+                    const real* __restrict__ par = sPar[q_];
+                    if (par[0] == real(0)) continue;
+                    const real t2 = sRW[q_][2 * ir], wt = sRW[q_][2 * ir + 1];
+                    const real inv_ = par[18], aij_ = par[19], akl_ = par[20];
+                    const real rt_aa = t2 * inv_;
+                    const real rt_aij = rt_aa * akl_, rt_akl = rt_aa * aij_;
+                    const real b10 = real(0.5) * par[21] * (real(1) - rt_aij);
+                    const real b01 = real(0.5) * par[22] * (real(1) - rt_akl);
+                    const real b00 = real(0.5) * rt_aa;
+                    const real g0 = ax == 0 ? par[1] : ax == 1 ? par[2] : wt;
+                    const real pa = par[3 + ax], qc = par[6 + ax], pq = par[9 + ax], dij = par[12 + ax], dkl = par[15 + ax];
+                    real* __restrict__ dst = &sExt[q_][ax][0];
+                    const real c0 = pa - rt_aij * pq, cp = qc + rt_akl * pq;
+                    switch (ie) {            // DI = LI + 2 <= 6 rows
+                    case 0: axis_row_g<0>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                    case 1: axis_row_g<1>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                    case 2: if (DI > 2) axis_row_g<(DI > 2 ? 2 : 0)>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                    case 3: if (DI > 3) axis_row_g<(DI > 3 ? 3 : 0)>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                    case 4: if (DI > 4) axis_row_g<(DI > 4 ? 4 : 0)>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                    default: if (DI > 5) axis_row_g<(DI > 5 ? 5 : 0)>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
+                    }
+                }
+#else
                 constexpr int NJOB = GRAD_A1_ROWS ? 3 * DI : 3;
                 if (act && !(GRAD_ABL & 32))
                     for (int job = lt; job < NJOB; job += T) {
@@ -722,26 +802,65 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         axis_integrals_g(g0, pa - rt_aij * pq, qc + rt_akl * pq, b10, b01, b00, dij, dkl, &sExt[sl][ax][0]);
 #endif
                     }
+#endif  // GRAD_A1_MAP
+                GSTAMP(2)
                 __syncthreads();
+                GSTAMP(3)
                 // ---- A2: derivative records {g, dg/dA, dg/dB, dg/dC} of every index tuple, all lanes of the quartet
-                if (act && !(GRAD_ABL & 16))
-                    for (int n = lt; n < 3 * GSB; n += T) {
-                        const int ax = n / GSB, b = n - ax * GSB;
-                        const int i = b / BI, j = (b / BJ) % (LJ + 1), k = (b / BK) % (LK + 1), l = b % (LL + 1);
-                        const real* __restrict__ g = &sExt[sl][ax][i * SI + j * SJ + k * SK + l];
+                if (act && !(GRAD_ABL & 16)) {
+                    // (index tuple and extended-array offset of each of the lane's records: worked out once per kernel, sRec)
+#pragma unroll
+                    for (int m = 0; m < NREC; m++) {
+                        const int rc = sRec[lt + m * T];
+                        if (rc < 0) continue;
+                        const int i = (rc >> 20) & 7, j = (rc >> 23) & 7, k = (rc >> 26) & 7;
+                        const real* __restrict__ g = &sExt[sl][0][0] + (rc & 0xfffff);
                         const real g0 = g[0];
-                        const real dA = ai2 * g[SI] - (i ? i * g[-SI] : real(0));
-                        const real dB = aj2 * g[SJ] - (j ? j * g[-SJ] : real(0));
-                        const real dC = ak2 * g[SK] - (k ? k * g[-SK] : real(0));
-                        real* __restrict__ q = &sQ[sl][ax][b][0];
+                        const real dA = ai2 * g[SI] - real(i) * g[i ? -SI : 0];
+                        const real dB = aj2 * g[SJ] - real(j) * g[j ? -SJ : 0];
+                        const real dC = ak2 * g[SK] - real(k) * g[k ? -SK : 0];
+                        real* __restrict__ q = &sQ[sl][0][0][0] + (lt + m * T) * 4;
                         q[0] = g0; q[1] = dA; q[2] = dB; q[3] = dC;
                     }
+                }
+                GSTAMP(4)
                 __syncthreads();
+                GSTAMP(5)
                 // ---- B: this lane's bra component pair against every ket component
                 if (act && !(GRAD_ABL & 8)) {
                     const real (*__restrict__ qx)[4] = sQ[sl][0];
                     const real (*__restrict__ qy)[4] = sQ[sl][1];
                     const real (*__restrict__ qz)[4] = sQ[sl][2];
+#if GRAD_COOP_W
+                    // W form (as in the one-quartet-per-lane form above): per ket component three 8-byte reads and three accumulators
+                    // indexed by the ket index tuple (compile-time indices: registers), then one 32-byte record per tuple and axis
+                    constexpr int NKT = (LK + 1) * (LL + 1);
+                    real wx[NKT], wy[NKT], wz[NKT];
+#pragma unroll
+                    for (int t = 0; t < NKT; t++) wx[t] = wy[t] = wz[t] = 0;
+#pragma unroll
+                    for (int k = 0; k < NFK; k++)
+#pragma unroll
+                    for (int l = 0; l < NFL; l++) {
+                        const int tx = TK.x[k] * BK + TL.x[l], ty = TK.y[k] * BK + TL.y[l], tz = TK.z[k] * BK + TL.z[l];
+                        real p;
+                        if (P_REGS) p = pkl[k * NFL + l];
+                        else {
+                            p = tij * sDkl[sl][k * NFL + l];
+                            for (int s = 0; s < NS_MAX; s++) p -= sik[s][k] * sjl[s][l] + sil[s][l] * sjk[s][k];
+                        }
+                        const real X = qx[bx0 + tx][0], Y = qy[by0 + ty][0], Z = qz[bz0 + tz][0];
+                        wx[tx] += p * (Y * Z);
+                        wy[ty] += p * (X * Z);
+                        wz[tz] += p * (X * Y);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NKT; t++) {
+                        gA[0] += wx[t] * qx[bx0 + t][1]; gB[0] += wx[t] * qx[bx0 + t][2]; gC[0] += wx[t] * qx[bx0 + t][3];
+                        gA[1] += wy[t] * qy[by0 + t][1]; gB[1] += wy[t] * qy[by0 + t][2]; gC[1] += wy[t] * qy[by0 + t][3];
+                        gA[2] += wz[t] * qz[bz0 + t][1]; gB[2] += wz[t] * qz[bz0 + t][2]; gC[2] += wz[t] * qz[bz0 + t][3];
+                    }
+#else
                     BUNROLL
                     for (int k = 0; k < NFK; k++)
                     BUNROLL
@@ -761,7 +880,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         gA[1] += pxz * qy[by][1]; gB[1] += pxz * qy[by][2]; gC[1] += pxz * qy[by][3];
                         gA[2] += pxy * qz[bz][1]; gB[2] += pxy * qz[bz][2]; gC[2] += pxy * qz[bz][3];
                     }
+#endif  // GRAD_COOP_W
                 }
+                GSTAMP(6)
                 // (the next A1 writes sExt only; its barrier separates this B from the next A2)
             }
         }
@@ -789,6 +910,12 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         const double v = sGA[n];
         if (v != 0.0) atomic_add_f64(gout + n, v);
     }
+#ifdef GRAD_STAMPS
+    GSTAMP(7)
+    if (blockIdx.x == 0 && tid == 0)
+        printf("stamps (cycles of s_memtime): pass setup %llu  combination setup + Rys %llu  A1 %llu  barrier %llu  A2 %llu  barrier %llu  B %llu  tail %llu\n",
+               st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+#endif
 }
 #else
 #ifndef GRAD_MINW

@@ -26,7 +26,7 @@ def setup(name, basis):
     return mol, lay, dm
 
 
-def check(mol, lay, dm, g=None, log=print):
+def check(mol, lay, dm, g=None, log=print, lr=True):
     """The six properties; returns {name: error} (relative to the largest J/K element except ``mixed``: absolute)."""
     import numpy as np, torch
     from joltqc_amd.backend import jk as router
@@ -52,7 +52,8 @@ def check(mol, lay, dm, g=None, log=print):
         res["queue_J"], res["queue_K"] = rel(j3, ref_j), rel(k3, ref_k)
         res["queue_n"], res["tile_n"] = g3.quartet_counts()[0], g.quartet_counts()[0]
         log(f"  (2) queue 1q1t kernels ({time.time()-t:.1f}s): dJ {res['queue_J']:.2e}  dK {res['queue_K']:.2e}  quartets {res['queue_n']} vs tiled {res['tile_n']}")
-        qj, qk = g3(mol, dm, hermi=1, omega=0.3)
+        if lr:
+            qj, qk = g3(mol, dm, hermi=1, omega=0.3)
         del os.environ["JQC_JK_ALGO"]; router.gen_jk_kernel.cache_clear()
         res["asym_J"], res["asym_K"] = rel(ref_j, ref_j.T), rel(ref_k, ref_k.T)
         log(f"  (3) asymmetry: J {res['asym_J']:.2e}  K {res['asym_K']:.2e}")
@@ -63,10 +64,11 @@ def check(mol, lay, dm, g=None, log=print):
         jb, kb = g(mol, dm + 0.5 * dm2, hermi=1)
         res["lin_J"], res["lin_K"] = rel(jb, ref_j + 0.5 * ja), rel(kb, ref_k + 0.5 * ka)
         log(f"  (4) linearity: J {res['lin_J']:.2e}  K {res['lin_K']:.2e}")
-        kj, kk = g(mol, dm, hermi=1, omega=0.3)
-        res["lr_J"], res["lr_K"] = rel(kj, qj), rel(kk, qk)
-        res["lr_Kmax"] = float(kk.abs().max())
-        log(f"  (5) omega=0.3 tiled vs queue: dJ {res['lr_J']:.2e}  dK {res['lr_K']:.2e}  |K_lr|max {res['lr_Kmax']:.3e}")
+        if lr:
+            kj, kk = g(mol, dm, hermi=1, omega=0.3)
+            res["lr_J"], res["lr_K"] = rel(kj, qj), rel(kk, qk)
+            res["lr_Kmax"] = float(kk.abs().max())
+            log(f"  (5) omega=0.3 tiled vs queue: dJ {res['lr_J']:.2e}  dK {res['lr_K']:.2e}  |K_lr|max {res['lr_Kmax']:.3e}")
         gm = jkmod.generate_jk_kernel(lay, cutoff_fp64=1e-7, cutoff_fp32=1e-13)
         mj, mk = gm(mol, dm, hermi=1)
         n64m, n32m, _ = gm.quartet_counts()
@@ -79,6 +81,7 @@ def check(mol, lay, dm, g=None, log=print):
         else:
             os.environ["JQC_JK_ALGO"] = saved
         router.gen_jk_kernel.cache_clear()
+    res["_ref"] = (ref_j, ref_k, g)
     return res
 
 
