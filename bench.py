@@ -25,6 +25,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 instead when it is importable on the box (it is not in this image).
   grid_path     rho / vxc (GGA) of the DFT grid path on the same molecule and basis with a Becke grid (own generator):
                 grid points x AO pairs per second and the fraction of the FP64 MFMA peak (N = 1 only).
+  forces        one two-electron gradient (jk_grad kernels) of the SCF-like density of the realistic_density
+                leg, next to that leg's J/K build (N = 1 only; one untimed call is not made: the kernels are built ahead of time).
 """
 import argparse
 import glob
@@ -514,6 +516,20 @@ def main():
                     "max_rel_dev_k": float((vk - ref_k).abs().max() / ref_k.abs().max())}
             except Exception as e:  # noqa: BLE001  (the headline must survive a failure of the extra leg)
                 out["realistic_density"]["mixed_precision"] = {"error": repr(e)[:300]}
+        if world == 1 and not args.no_grid and "realistic_density" in out:
+            try:
+                from joltqc_amd.pyscf import grad as gradmod
+                fn = gradmod.generate_jk_energy_per_atom(layout, cutoff=1e-13)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                g2 = fn(mol, dm2)
+                torch.cuda.synchronize()
+                dtg = time.perf_counter() - t1
+                out["forces"] = {"two_electron_gradient_ms": dtg * 1e3, "quartets": float(fn.quartet_count()),
+                                 "jk_builds_of_the_same_density": dtg / out["realistic_density"]["ms_per_step"] * 1e3,
+                                 "finite": bool(torch.isfinite(g2).all()), "launches": int(fn.stats["launches"])}
+            except Exception as e:  # noqa: BLE001  (the headline must survive a failure of the extra leg)
+                out["forces"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_grid:
             try:
                 out["grid_path"] = grid_leg(mol)

@@ -98,8 +98,8 @@ def test_get_ecp_ipip_against_the_oracle(ip_type, cart):
     lay = BasisLayout.from_mol(mol, alignment=1)
     got = becp.get_ecp_ipip(mol, ip_type=ip_type).cpu().numpy()
     assert got.shape == (2, 9, mol.nao, mol.nao)
-    # (the oracle's AO Hessians make "ipipv" the slow leg: both ECP atoms in the Cartesian basis, one in the spherical one)
-    for n, atom in enumerate((0, 1) if (cart or ip_type == "ipvip") else (1,)):
+    # (the oracle's AO Hessians make "ipipv" the slow leg: one ECP atom there, both for "ipvip")
+    for n, atom in enumerate((0, 1) if ip_type == "ipvip" else (1,)):
         n = atom
         ref = oecp.ecp_ipip_mol(lay, mol, atom, ip_type, nang=32, nrad=32)
         scale = np.abs(ref).max()

@@ -373,7 +373,7 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
         # (three atoms 2-3 Bohr apart and a density of O(10) elements: the estimates Q_ij Q_kl |D| of this system lie around 1e0 - 1e2)
         cut64, tol = (1e20, 2e-5) if mode == "fused32" else (30.0, 2e-5)
     bad, nclass, nfused, nboth = [], 0, 0, 0
-    lmax = 3 if dm.ndim == 3 and dm.shape[0] == 3 else 4      # (three matrices: s..f, the odd-tail logic is the same for g)
+    lmax = 2 if dm.ndim == 3 and dm.shape[0] == 3 else 4      # (three matrices: s..d -- the pair builds of every class run in jk_2dm, the odd-tail logic is the same for f, g)
     get_jk = jkmod.generate_jk_kernel(lay, cutoff_fp64=cut64, cutoff_fp32=1e-13)
     try:
         for li in range(lmax + 1):
@@ -407,7 +407,7 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
                                     bad.append((key, "dm%d" % (m + 1), e2))
     finally:
         os.environ.pop("JQC_ONLY_CLASS", None)
-    assert nclass == (140 if lmax == 4 else 65) and not bad, bad
+    assert nclass == (140 if lmax == 4 else 25) and not bad, bad
     if fused:                   # the packed-FP32 phase did run in the lane-per-quartet classes (46 of the 140 in the main table)
         # (measured: 21 classes, both phases in 9; before nine classes moved to the quad form, which has no fused build: 29-30 and 12)
         assert nfused >= 18 and (mode != "fused" or nboth >= 7), (nfused, nboth)
