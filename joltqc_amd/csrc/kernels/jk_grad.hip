@@ -596,7 +596,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         sRec[n] = n < 3 * GSB ? ((ax * GSZ + i * SI + j * SJ + k * SK + l) | (i << 20) | (j << 23) | (k << 26)) : -1;
     }
 #ifdef GRAD_STAMPS       // cycle counts of the phases of workgroup 0 (wave 0), printed at the end: tools/grad_ab.py with -DGRAD_STAMPS=1
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+    unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
 #define GSTAMP(n) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[n] += t_ - st_t; st_t = t_; }
 #else
 #define GSTAMP(n)
@@ -655,19 +655,31 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             }
         }
         tij *= real(4) * jfac;
-        __syncthreads();                               // the previous pass has left sAcc / sDkl / s_ncomb
-        if (tid == 0) s_ncomb = 0;
-        if (on) {
-            for (int n = lt; n < NFK * NFL; n += T) {
-                real v = 0;
+        GSTAMP(9)
+        // D_kl of the quartet (shared by its lanes through LDS): requested together with the lane's own gathers above, stored after the
+        // barrier -- one global-load level and one barrier less per pass than gathering it after the barrier
+        constexpr int NKLV = (NFK * NFL + T - 1) / T;
+        real dklv[NKLV];
+#pragma unroll
+        for (int m = 0; m < NKLV; m++) {
+            const int n = lt + m * T;
+            real v = 0;
+            if (on && n < NFK * NFL)
                 for (int s = 0; s < n_dm; s++) v += dm[s * nao2 + (size_t)(k0 + n / NFL) * nao + l0 + n % NFL];
-                sDkl[sl][n] = v;
-            }
+            dklv[m] = v;
+        }
+        if (tid == 0) s_ncomb = 0;                     // (its readers of the previous pass are behind that pass's last barrier)
+        GSTAMP(10)
+        __syncthreads();
+        GSTAMP(11)                               // the previous pass has left sAcc / sDkl
+        if (on) {
+#pragma unroll
+            for (int m = 0; m < NKLV; m++)
+                if (lt + m * T < NFK * NFL) sDkl[sl][lt + m * T] = dklv[m];
+            if (lt == 0) atomicMax(&s_ncomb, ncomb);
         }
         if (lane_on)
             for (int n = lt; n < 9; n += T) sAcc[sl][n] = 0;
-        __syncthreads();
-        if (on && lt == 0) atomicMax(&s_ncomb, ncomb);
         __syncthreads();
         const int ncomb_max = s_ncomb;
 
@@ -887,6 +899,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
             }
         }
         // ---- sum over the quartet's lanes in LDS, then twelve global atomics per quartet
+        GSTAMP(8)
         if (on) {
 #pragma unroll
             for (int x = 0; x < 3; x++) {
@@ -913,8 +926,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #ifdef GRAD_STAMPS
     GSTAMP(7)
     if (blockIdx.x == 0 && tid == 0)
-        printf("stamps (cycles of s_memtime): pass setup %llu  combination setup + Rys %llu  A1 %llu  barrier %llu  A2 %llu  barrier %llu  B %llu  tail %llu\n",
-               st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+        printf("stamps (cycles of s_memtime): pass setup after its first barrier %llu  combination setup + Rys %llu  A1 %llu  barrier %llu  A2 %llu  barrier %llu  B %llu  tail %llu"
+               "  (loop tail of B %llu)  previous pass's reduction + flush + this pass's quartet, rows, density gathers issued %llu  D_kl gathers %llu  first barrier %llu\n",
+               st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11]);
 #endif
 }
 #else

@@ -146,6 +146,48 @@ def test_112_atoms_svp_directional_derivative_and_default_cutoff():
     assert np.abs(g13 - g10).max() < 1e-6 * np.abs(g13).max()
 
 
+@pytest.mark.parametrize("kind", ["lane", "cooperative"])
+def test_per_atom_lds_tables_and_their_overflow_paths(kind):
+    """The gradient kernels accumulate into a per-atom table in LDS (1 024 atoms in the one-quartet-per-lane form, 256 in the
+    cooperative form); atoms beyond the table go to global memory directly.  Lattices with MORE atoms than the tables hold -- 1 100 He
+    atoms with one s function (class (ss|ss): lane form), 300 with s, p, d functions (the d classes: cooperative form) -- and the same
+    lattice with its atoms in REVERSED order, so that every atom changes sides of the table boundary: the gradient must come out
+    permuted (1e-11 of the largest component), sum to zero over the atoms, and differ from zero."""
+    import torch
+    from joltqc_amd.gto import mole
+    from joltqc_amd.pyscf import grad
+    from joltqc_amd.pyscf.basis import BasisLayout
+    rng = np.random.default_rng(17)
+    if kind == "lane":
+        n1, basis = 11, {"He": [[0, [0.9, 1.0]]]}                                   # 11 x 10 x 10 = 1 100 atoms
+        xyz = np.array([(a, b, c) for a in range(n1) for b in range(10) for c in range(10)], dtype=float) * 3.2
+    else:
+        basis = {"He": [[0, [1.1, 1.0]], [1, [0.9, 1.0]], [2, [1.0, 1.0]]]}
+        xyz = np.array([(a, b, c) for a in range(10) for b in range(6) for c in range(5)], dtype=float) * 3.6   # 300 atoms
+    xyz = xyz + rng.normal(size=xyz.shape) * 0.15
+    natm = len(xyz)
+    out = []
+    for order in (np.arange(natm), np.arange(natm)[::-1]):
+        mol = mole.Mole(atom=[("He", tuple(xyz[a])) for a in order], basis=basis, unit="B")
+        lay = BasisLayout.from_mol(mol, alignment=1)
+        nao = mol.nao
+        per = nao // natm
+        # a density that is the same function of the ATOMS in both orders: block (a, b) depends on the atoms' lattice identities
+        blocks = np.random.default_rng(3).random((per, per)) - 0.4
+        w = np.exp(-0.08 * np.linalg.norm(xyz[order][:, None] - xyz[order][None], axis=2) ** 2)
+        dm = np.kron(w, blocks + blocks.T)
+        fn = grad.generate_jk_energy_per_atom(lay, cutoff=1e-12)
+        g = _np(fn(mol, torch.from_numpy(dm).cuda()))
+        assert g.shape == (natm, 3) and np.isfinite(g).all()
+        back = np.empty_like(g)
+        back[order] = g                                                             # gradient per LATTICE atom
+        out.append(back)
+    scale = np.abs(out[0]).max()
+    assert scale > 1e-3
+    assert np.abs(out[0].sum(axis=0)).max() < 1e-10 * scale * natm
+    assert np.abs(out[0] - out[1]).max() < 1e-11 * scale, np.abs(out[0] - out[1]).max() / scale
+
+
 def test_rhf_forces_through_apply_match_finite_differences_of_the_scf_energy():
     """End to end on H2O / def2-SVP: apply() installs ``_jqc_jk_energy_per_atom``; with the one-electron, overlap and nuclear
     terms differentiated numerically at FIXED density (cheap CPU integrals) the force along a random displacement equals the
