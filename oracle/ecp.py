@@ -8,7 +8,8 @@ the kernels ``ecp/ecp_type1.cu`` / ``ecp_type2.cu`` evaluate it semi-analyticall
 with the local channel U_L (``ANG_OF = -1``) acting on everything and the semi-local channels through the projectors onto the
 spherical harmonics around C.  The reference's own tests compare against libcint's ``mol.intor("ECPscalar")``
 (``jqc/pyscf/tests/test_ecp_small.py:118-131``); libcint and PySCF are third party and absent from this image, and the tests
-hold no stored numbers, so NO reference-held value pins this row: the oracle is the definition evaluated by plain quadrature,
+hold no stored integrals (one total energy depends on them: I2 / def2-TZVPP + def2 ECP, PBE, -582.7625143308, test_dft_ecp.py:52-56 -- iodine's
+basis and ECP tables are not in this image), so NO reference-held value pins this row: the oracle is the definition evaluated by plain quadrature,
 checked against closed forms where they exist (tests/test_ecp_oracle.py).
 
 Method (deliberately different from the device kernels: no Bessel functions, no angular tables, no binomial expansions):
