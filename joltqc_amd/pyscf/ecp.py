@@ -3,8 +3,8 @@
 ``apply_ecp(mol)`` returns ``{"get_ecp": closure, "ecp_kernel": launcher info, "precision": "fp64", "original_methods": {}}``
 (empty dict for a molecule without ECP), ``patch_ecp_integrals(mol)`` installs ``mol.get_ecp`` in place and records
 ``mol._jqc_ecp_info``, ``restore_ecp_methods(mol)`` undoes it.  The integrals come from ``joltqc_amd.backend.ecp.get_ecp``
-(device kernel ``ecp_scalar_kernel``); only the scalar potential matrix is built -- the reference's derivative generators
-(``get_ecp_ip`` / ``get_ecp_ipip``) have no counterpart yet.
+(device kernel ``ecp_scalar_kernel``); like the reference's module this one patches the scalar potential matrix only -- the derivative
+integrals are called directly: ``joltqc_amd.backend.ecp.get_ecp_ip`` / ``get_ecp_ipip`` (reference ``jqc/backend/ecp.py:953-1340``).
 """
 from typing import Any, Dict
 
