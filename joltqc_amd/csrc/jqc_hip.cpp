@@ -846,10 +846,13 @@ static int grad_quartets_per_pass(int li, int lj, int lk, int ll)
 {
     auto nf = [](int l) { return (l + 1) * (l + 2) / 2; };
     const int t = nf(li) * nf(lj);
-    const int gsz = (li + 2) * (lj + 2) * (lk + 2) * (ll + 1), gsb = (li + 1) * (lj + 1) * (lk + 1) * (ll + 1);
+    const int gsz = (li + 2) * (lj + 2) * (lk + 2) * (ll + 1);
+    const int nkt = (lk + 1) * (ll + 1);
+    const int gsb = (li + 1) * (lj + 1) * (nkt % 4 == 0 ? nkt + 1 : nkt);          // (CGSB: record index space with the padded j stride)
     const int nrg = (li + lj + lk + ll + 1) / 2 + 1;
     static const bool a1_map_off = getenv("JQC_EXTRA_DEFS") && strstr(getenv("JQC_EXTRA_DEFS"), "-DGRAD_A1_MAP=0");      // (A/B builds)
-    const int qbytes = (3 * (gsz + 4 * gsb) + 2 * nrg + nf(lk) * nf(ll) + 9 + (a1_map_off ? 0 : 24)) * 8;      // (+ NPAR: sPar)
+    static const char* qpad_s = getenv("JQC_EXTRA_DEFS") ? strstr(getenv("JQC_EXTRA_DEFS"), "-DQPAD=") : nullptr;                 // (A/B builds)
+    const int qbytes = (3 * (gsz + 4 * gsb) + (qpad_s ? atoi(qpad_s + 7) : 2) + ((6 * gsz) % 32 == 0 ? 1 : 0) + 2 * nrg + nf(lk) * nf(ll) + 9 + (a1_map_off ? 0 : 24)) * 8;      // (+ QPAD, EPAD: bank padding of sQ / sExt, + NPAR: sPar)
     auto gcap = [&](int budget) { const int g = budget / qbytes; return g < 256 / t ? (g < 1 ? 1 : g) : 256 / t; };
     static const bool two_wg_off = getenv("JQC_EXTRA_DEFS") && strstr(getenv("JQC_EXTRA_DEFS"), "-DGRAD_TWO_WG=0");
     const bool two_wg = !two_wg_off && nf(lk) * nf(ll) <= 18 && 4 * gcap(72 * 1024) >= 3 * gcap(150 * 1024);
@@ -862,14 +865,14 @@ int jqc_gen_jk_grad_kernel(int li, int lj, int lk, int ll, int rys_lr, int compi
     if (li > JQC_LMAX || lj > li || lk > li || ll > lk || li < 0 || lj < 0 || lk < 0 || ll < 0)
         return fail(-1, "unsupported angular class (%d%d|%d%d): need LMAX>=li>=lj, li>=lk>=ll", li, lj, lk, ll);
     // Which form (jk_grad.hip): the cooperative one (GRAD_COOP) where it measured faster on the 112-atom def2-TZVPP gradient
-    // (32 of the 65 s..f classes, profiles/r05_grad_forms_per_class_112atoms_tzvpp.txt -- round 5, after the one-quartet-per-lane
+    // (36 of the 65 s..f classes, profiles/r05_grad_forms_per_class_112atoms_tzvpp.txt -- round 5, after the one-quartet-per-lane
     // form got its LDS per-atom table, block-wise density reads and the W form: everything from 324 integrals with a p, d or f
     // ket pair, and (dp|pp)), the one-quartet-per-lane form for the rest.  g classes (not in that workload): by the size of the ket block.
     // JQC_GRAD_COOP=0 / 1 forces one form on every class (A/B).
     static const int coop_env = getenv("JQC_GRAD_COOP") ? atoi(getenv("JQC_GRAD_COOP")) : -1;
-    static const char* const kCoopWins[] = {"2111", "2121", "2122", "2211", "2221", "2222", "3022", "3031", "3032", "3111", "3121", "3122",
-        "3130", "3131", "3132", "3133", "3211", "3220", "3221", "3222", "3230", "3231", "3232", "3233", "3311", "3320", "3321", "3322",
-        "3330", "3331", "3332", "3333"};
+    static const char* const kCoopWins[] = {"2022", "2111", "2121", "2122", "2211", "2220", "2221", "2222", "3021", "3022", "3031", "3032",
+        "3033", "3111", "3121", "3122", "3130", "3131", "3132", "3133", "3211", "3220", "3221", "3222", "3230", "3231", "3232", "3233",
+        "3311", "3320", "3321", "3322", "3330", "3331", "3332", "3333"};
     int coop = coop_env;
     if (coop < 0) {
         if (li <= 3) {

@@ -448,7 +448,16 @@ constexpr int T = NFI * NFJ;
 #define GRAD_A1_MAP 1     // phase-A1 jobs dealt over the whole workgroup ordered by row (see A1 below); needs the quartets' parameters in LDS
 #endif
 constexpr int NPAR = 24;  // per-quartet parameters of the current primitive combination (sPar)
-constexpr int QBYTES = (3 * (GSZ + 4 * GSB) + 2 * NRG + NFK * NFL + 9 + (GRAD_A1_MAP ? NPAR : 0)) * 8;
+#ifndef QPAD
+#define QPAD 2    // doubles between the record slots of two quartets (16 bytes: the records stay 16-byte aligned for ds_read_b128; an 8-byte pad cost 25 %)
+#endif
+// The records themselves are indexed i * CBI + j * CBJ + k * BK + l with CBJ one more than the dense stride where that is a multiple of 4: with the dense stride (BJ = 4 for a (pp) ket) the records of
+// the bra index tuples a quartet's lanes read in one instruction start 32 LDS banks apart -- two bank groups for six addresses.
+// (measured: stride 4 -> 5 and 8 -> 9 win -- (fd|pp) 585 -> 536 ms, (fp|fp) 275 -> 233 --, 6 -> 7 loses its LDS to fewer quartets per pass -- (dp|dp) 576 -> 726)
+constexpr int CBJ = ((LK + 1) * BK) % 4 == 0 ? (LK + 1) * BK + 1 : (LK + 1) * BK, CBI = (LJ + 1) * CBJ, CGSB = (LI + 1) * CBI;
+// ... and one double between their extended arrays where those would start 0 or 32 banks apart
+constexpr int EPAD = (6 * GSZ) % 32 == 0 ? 1 : 0;
+constexpr int QBYTES = (3 * (GSZ + 4 * CGSB) + QPAD + EPAD + 2 * NRG + NFK * NFL + 9 + (GRAD_A1_MAP ? NPAR : 0)) * 8;
 constexpr int gcap(int budget) { return budget / QBYTES < 256 / T ? (budget / QBYTES < 1 ? 1 : budget / QBYTES) : 256 / T; }
 #ifndef GRAD_TWO_WG
 #define GRAD_TWO_WG 1
@@ -567,13 +576,15 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
       const ushort4* __restrict__ quartets, const unsigned* __restrict__ ntasks_ptr, const int qstride,
       const real* __restrict__ rys_cheb, const real* __restrict__ rys_large)
 {
-    __shared__ real sExt[G][3][GSZ];                                   // extended 1-D arrays of the current (combination, root)
-    __shared__ __attribute__((aligned(32))) real sQ[G][3][GSB][4];     // derivative records of the same
+    __shared__ real sExt[G][3 * GSZ + EPAD];                           // extended 1-D arrays of the current (combination, root)
+    // derivative records of the same.  QPAD: 96 GSB bytes is a multiple of 256 for most classes, which put the records of all quartets of a wave on
+    // the same LDS banks (bank conflicts on half of the LDS cycles, profiles/r05_pmc_grad_class_kernels_112atoms.txt): slots 16 bytes further apart
+    __shared__ __attribute__((aligned(32))) real sQ[G][3 * CGSB * 4 + QPAD];
     __shared__ real sRW[G][2 * NRG];
     __shared__ real sDkl[G][NFK * NFL];
     __shared__ double sAcc[G][9];
     __shared__ real sPar[GRAD_A1_MAP ? G : 1][NPAR];
-    __shared__ int sRec[((3 * GSB + T - 1) / T) * T];
+    __shared__ int sRec[((3 * GSB + T - 1) / T) * T], sRecQ[((3 * GSB + T - 1) / T) * T];
     __shared__ double sGA[LDS_ATOMS_COOP * 3];     // per-atom sums of this workgroup (atoms below LDS_ATOMS_COOP), flushed once at the end
     __shared__ int s_ncomb;
     const int tid = threadIdx.x;
@@ -586,7 +597,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     const size_t nao2 = (size_t)nao * nao;
     const real kscale = kfac * n_dm;
     // index bases of this lane's bra component pair inside the record arrays
-    const int bx0 = TI.x[ci] * BI + TJ.x[cj] * BJ, by0 = TI.y[ci] * BI + TJ.y[cj] * BJ, bz0 = TI.z[ci] * BI + TJ.z[cj] * BJ;
+    const int bx0 = TI.x[ci] * CBI + TJ.x[cj] * CBJ, by0 = TI.y[ci] * CBI + TJ.y[cj] * CBJ, bz0 = TI.z[ci] * CBI + TJ.z[cj] * CBJ;
     // phase A2: the records lane lt of a quartet builds per root (n = lt + m T < 3 GSB), as offset into sExt[slot] | i << 20 | j << 23 |
     // k << 26: a table in LDS shared by the quartets (in registers it cost the 256-register builds spills: (dp|dp) 677 -> 841 ms)
     constexpr int NREC = (3 * GSB + T - 1) / T;
@@ -594,6 +605,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
         const int ax = n / GSB, b = n - ax * GSB;
         const int i = b / BI, j = (b / BJ) % (LJ + 1), k = (b / BK) % (LK + 1), l = b % (LL + 1);
         sRec[n] = n < 3 * GSB ? ((ax * GSZ + i * SI + j * SJ + k * SK + l) | (i << 20) | (j << 23) | (k << 26)) : -1;
+        sRecQ[n] = (ax * CGSB + i * CBI + j * CBJ + k * BK + l) * 4;          // where the record goes in sQ[slot]
     }
 #ifdef GRAD_STAMPS       // cycle counts of the phases of workgroup 0 (wave 0), printed at the end: tools/grad_ab.py with -DGRAD_STAMPS=1
     unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
@@ -771,7 +783,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     const real b00 = real(0.5) * rt_aa;
                     const real g0 = ax == 0 ? par[1] : ax == 1 ? par[2] : wt;
                     const real pa = par[3 + ax], qc = par[6 + ax], pq = par[9 + ax], dij = par[12 + ax], dkl = par[15 + ax];
-                    real* __restrict__ dst = &sExt[q_][ax][0];
+                    real* __restrict__ dst = &sExt[q_][ax * GSZ];
                     const real c0 = pa - rt_aij * pq, cp = qc + rt_akl * pq;
                     switch (ie) {            // DI = LI + 2 <= 6 rows
                     case 0: axis_row_g<0>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
@@ -800,7 +812,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         const real dij = ax == 0 ? rij[0] : ax == 1 ? rij[1] : rij[2];
                         const real dkl = ax == 0 ? rkl[0] : ax == 1 ? rkl[1] : rkl[2];
 #if GRAD_A1_ROWS
-                        real* __restrict__ dst = &sExt[sl][ax][0];
+                        real* __restrict__ dst = &sExt[sl][ax * GSZ];
                         const real c0 = pa - rt_aij * pq, cp = qc + rt_akl * pq;
                         switch (ie) {            // DI = LI + 2 <= 6 rows
                         case 0: axis_row_g<0>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
@@ -811,7 +823,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         default: if (DI > 5) axis_row_g<(DI > 5 ? 5 : 0)>(g0, c0, cp, b10, b01, b00, dij, dkl, dst); break;
                         }
 #else
-                        axis_integrals_g(g0, pa - rt_aij * pq, qc + rt_akl * pq, b10, b01, b00, dij, dkl, &sExt[sl][ax][0]);
+                        axis_integrals_g(g0, pa - rt_aij * pq, qc + rt_akl * pq, b10, b01, b00, dij, dkl, &sExt[sl][ax * GSZ]);
 #endif
                     }
 #endif  // GRAD_A1_MAP
@@ -826,12 +838,12 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         const int rc = sRec[lt + m * T];
                         if (rc < 0) continue;
                         const int i = (rc >> 20) & 7, j = (rc >> 23) & 7, k = (rc >> 26) & 7;
-                        const real* __restrict__ g = &sExt[sl][0][0] + (rc & 0xfffff);
+                        const real* __restrict__ g = &sExt[sl][0] + (rc & 0xfffff);
                         const real g0 = g[0];
                         const real dA = ai2 * g[SI] - real(i) * g[i ? -SI : 0];
                         const real dB = aj2 * g[SJ] - real(j) * g[j ? -SJ : 0];
                         const real dC = ak2 * g[SK] - real(k) * g[k ? -SK : 0];
-                        real* __restrict__ q = &sQ[sl][0][0][0] + (lt + m * T) * 4;
+                        real* __restrict__ q = &sQ[sl][0] + sRecQ[lt + m * T];
                         q[0] = g0; q[1] = dA; q[2] = dB; q[3] = dC;
                     }
                 }
@@ -840,9 +852,9 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                 GSTAMP(5)
                 // ---- B: this lane's bra component pair against every ket component
                 if (act && !(GRAD_ABL & 8)) {
-                    const real (*__restrict__ qx)[4] = sQ[sl][0];
-                    const real (*__restrict__ qy)[4] = sQ[sl][1];
-                    const real (*__restrict__ qz)[4] = sQ[sl][2];
+                    const real (*__restrict__ qx)[4] = reinterpret_cast<const real (*)[4]>(&sQ[sl][0]);
+                    const real (*__restrict__ qy)[4] = qx + CGSB;
+                    const real (*__restrict__ qz)[4] = qx + 2 * CGSB;
 #if GRAD_COOP_W
                     // W form (as in the one-quartet-per-lane form above): per ket component three 8-byte reads and three accumulators
                     // indexed by the ket index tuple (compile-time indices: registers), then one 32-byte record per tuple and axis
