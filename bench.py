@@ -23,6 +23,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline  the CPU oracle (C restatement of the reference arithmetic, OpenMP over os.cpu_count() host cores) on a
                 bounded sample drawn from the dispatched class histogram of this workload; PySCF's get_jk is used
                 instead when it is importable on the box (it is not in this image).
+  parity        max|dJ|, max|dK| of the timed workload's own result against the CPU oracle on a fixed sample of shell blocks
+                (every quartet those blocks need: oracle/dense.py:sampled_blocks), outside the timed region.
   grid_path     rho / vxc (GGA) of the DFT grid path on the same molecule and basis with a Becke grid (own generator):
                 grid points x AO pairs per second and the fraction of the FP64 MFMA peak (N = 1 only).
   forces        one two-electron gradient (jk_grad kernels) of the SCF-like density of the realistic_density
@@ -180,6 +182,57 @@ def cpu_baseline(mol, layout, per_class, seconds=12.0):
                       f"(no atomics, no Python in the timed region)"}
 
 
+def internal_jk(mol, get_jk, dm):
+    """One more (untimed) call that keeps J and K in the internal AO order (every rank: the call holds the path's collective)."""
+    get_jk.keep_internal = True
+    get_jk(mol, dm, hermi=1)
+    get_jk.keep_internal = False
+    return get_jk.stats.pop("vj_internal")[0], get_jk.stats.pop("vk_internal")[0]
+
+
+def parity_blocks(mol, layout, internal, dm, nthreads):
+    """max|dJ|, max|dK| of the timed workload's result against the CPU oracle on a fixed sample of shell blocks in the internal AO
+    order (reference bar jqc/pyscf/tests/test_jk.py:83-84: 1e-9 for FP64).  A block needs O(N^2) quartets
+    (oracle/dense.py:sampled_blocks), so a handful finishes in seconds where a full oracle build would take hours.  Outside every
+    timed region.  The sample: the highest-l shell against shells of every other angular momentum, plus s / p pairs."""
+    from oracle import dense
+    T = layout.transform_matrix()
+    dm_int = T @ dm.cpu().numpy() @ T.T
+    real = np.nonzero(~layout.pad_id)[0]
+    by_l = {}
+    for s_ in real:
+        by_l.setdefault(int(layout.angs[s_]), []).append(int(s_))
+    ls = sorted(by_l)
+    rng = np.random.default_rng(6)
+    pick = lambda l: int(rng.choice(by_l[l]))
+    top = ls[-1]
+    j_pairs, k_pairs = [], []
+    for l in ls:                                                # (f|l) ... blocks + one low-l pair
+        a, b = pick(top), pick(l)
+        j_pairs.append((max(a, b), min(a, b)))
+        a, b = pick(top), pick(l)
+        k_pairs.append((a, b))
+    j_pairs.append(tuple(sorted((pick(ls[0]), pick(ls[min(1, len(ls) - 1)])), reverse=True)))
+    k_pairs.append((pick(ls[min(1, len(ls) - 1)]), pick(ls[min(1, len(ls) - 1)])))
+    vj, vk = internal
+    t0 = time.perf_counter()
+    oj, ok = dense.sampled_blocks(layout, dm_int, j_pairs, k_pairs, nthreads=nthreads)
+    dt = time.perf_counter() - t0
+    loc = np.asarray(layout.ao_loc)
+    blk = lambda m, i, j: m[int(loc[i]):int(loc[i + 1]), int(loc[j]):int(loc[j + 1])].cpu().numpy()
+    dj = max(float(np.abs(blk(vj, i, j) - b).max()) for (i, j), b in oj.items())
+    dk = max(float(np.abs(blk(vk, i, k) - b).max()) for (i, k), b in ok.items())
+    sj = max(float(np.abs(b).max()) for b in oj.values())
+    sk = max(float(np.abs(b).max()) for b in ok.values())
+    nq = len(real) * (len(real) + 1) // 2 * len(j_pairs) + len(real) ** 2 * len(k_pairs)
+    return {"max_abs_dJ": dj, "max_abs_dK": dk, "max_abs_J": sj, "max_abs_K": sk, "blocks": len(oj) + len(ok),
+            "block_classes": {"J": ["(%d%d|" % (layout.angs[i], layout.angs[j]) for i, j in j_pairs],
+                              "K": ["(%d.|%d." % (layout.angs[i], layout.angs[k]) for i, k in k_pairs]},
+            "oracle_quartets": int(nq), "oracle_seconds": round(dt, 2), "bar": 1e-9,
+            "how": "shell blocks of J and K of the timed workload (internal AO order, after the epilogue) against oracle/dense.py:"
+                   "sampled_blocks -- every quartet a block needs, same C oracle as the parity tests; outside the timed region"}
+
+
 def committed_traffic(kernel):
     """HBM bytes per launch of ``kernel`` from the newest committed PMC summary that lists it."""
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
@@ -307,6 +360,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grid", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
     small = args.workload.startswith("benzene")
     steps = args.steps if args.steps is not None else (20 if small else 5)
@@ -403,6 +457,8 @@ def main():
         get_jk(mol, dm, hermi=1, _classes=lambda a: False)
     torch.cuda.synchronize()
     host_serial_ms = (time.perf_counter() - th) / 3 * 1e3
+    get_jk.set_streams(None)
+    internal = None if args.no_parity else internal_jk(mol, get_jk, dm)
     per_rank = None
     if world > 1:
         # diagnosability of the scaling curve: what every rank did -- its kernels' serial time, its quartets, the one Fock
@@ -431,8 +487,9 @@ def main():
         dom = max(tm, key=tm.get)
         kern_ms = tm[dom]
         achieved = flops_by_ang.get(dom, 0) / (kern_ms * 1e-3) / 1e12
-        mode = router.select_algo(dom, small=False) & 0xf
-        kname = ("jk_tile1q_" if mode == 2 else "jk_tile512_" if mode == 3 else "jk_tile_") + "%d%d%d%d" % dom
+        sel = router.select_algo(dom, small=False)
+        mode = sel & 0xf
+        kname = (("jk_quad_" if sel & (1 << 24) else "jk_tile1q_") if mode == 2 else "jk_tile512_" if mode == 3 else "jk_tile_") + "%d%d%d%d" % dom
         best = max(tm, key=lambda a: flops_by_ang.get(a, 0) / tm[a])
         out = {
             "metric": "ERI quartets/s (J/K Fock build, def2-TZVPP)", "value": quartets * steps / dt,
@@ -478,6 +535,18 @@ def main():
         if tr:
             out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
             out["roofline"]["traffic_detail"] = tr
+            nq1 = float(tr.get("quartets") or 0)
+            if world > 1 and nq1 > 0:
+                # the committed counters are of the one-rank launch of this kernel; a rank of an N-rank run launches it over its share
+                # of the class's task rows: HBM bytes scaled by the quartets this rank's launch processed (counter runs need one rank)
+                share = count_by_ang.get(dom, 0) / nq1
+                out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch") * share
+                out["roofline"]["traffic_detail"] = dict(tr, scaled_by_quartet_share_of_this_rank=share)
+        if internal is not None:
+            try:
+                out["parity"] = parity_blocks(mol, layout, internal, dm, physical_cores())
+            except Exception as e:  # noqa: BLE001  (the headline must survive a failure of the extra leg)
+                out["parity"] = {"error": repr(e)[:300]}
         if world == 1:
             # the dense density above disables density screening (as the reference's ones-D benchmark does); the same
             # build with a density of SCF-like decay, D = C C^T / n_occ, for orientation (not `value`)
@@ -535,7 +604,7 @@ def main():
                 out["grid_path"] = grid_leg(mol)
             except Exception as e:  # noqa: BLE001  (the headline must survive a failure of the extra leg)
                 out["grid_path"] = {"error": repr(e)[:300]}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:          # (N > 1: on rank 0 only, after the collectives of the timed region are over)
             out["cpu_baseline"] = cpu_baseline(mol, layout, per)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -67,6 +67,10 @@ def channels(mol):
     eb = np.asarray(getattr(mol, "_ecpbas", np.zeros((0, ECPBAS_SLOTS), dtype=np.int32)))
     env = np.asarray(mol._env)
     for r in eb:
+        # scalar potential only: spin-orbit rows (SO_TYPE_OF != 0, e.g. crenbl / crenbs potentials) are dropped, as the reference
+        # does before it sorts the rows (/root/reference/jqc/backend/ecp.py:1313-1315) and as libcint's ECPscalar does
+        if int(r[SO_TYPE_OF]) != 0:
+            continue
         n = int(r[NPRIM_OF])
         out.setdefault(int(r[ATOM_OF]), []).append((int(r[ANG_OF]), int(r[RADI_POWER]),
                                                     env[r[PTR_EXP]:r[PTR_EXP] + n].copy(), env[r[PTR_COEFF]:r[PTR_COEFF] + n].copy()))

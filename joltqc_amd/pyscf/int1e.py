@@ -45,9 +45,15 @@ def generate_get_hcore(layout, numpy_out=True):
     what ``pyscf.scf.hf.get_hcore`` adds through ``mol.intor("ECPscalar")``; here from ``backend.ecp.get_ecp`` (the nuclear
     charges in ``mol._atm`` are already lowered by the core electrons, as PySCF lowers them)."""
     def get_hcore(mol=None):
-        _, T, V = int1e(layout, mol)
-        h = T + V
         m = mol if mol is not None else layout._mol
+        # T, S and the ECP matrix are evaluated on the LAYOUT's shells and ECP centres: a different molecule (a scanner's
+        # displaced geometry) needs its own layout -- `apply()` builds one per geometry -- and is refused here rather than mixed
+        if m is not layout._mol and not (np.allclose(np.asarray(m.atom_coords()), np.asarray(layout._mol.atom_coords()), atol=1e-12)
+                                         and np.array_equal(np.asarray(getattr(m, "_ecpbas", ())), np.asarray(getattr(layout._mol, "_ecpbas", ())))):
+            raise ValueError("get_hcore(mol): the molecule differs from the one this layout was built from; call apply() / reset() "
+                             "for the new geometry")
+        _, T, V = int1e(layout, m)
+        h = T + V
         if len(getattr(m, "_ecpbas", ())) > 0:
             from ..backend import ecp as _ecp
             h = h + _ecp.get_ecp(layout)

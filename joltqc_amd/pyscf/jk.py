@@ -797,7 +797,9 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
         if need_queue:
             run_queue(want_q, vj_p, vk_p, log_cutoff_fp32, log_cutoff_fp64, mixed, shard, True)
 
-        if shard is not None and shard[1] > 1:
+        if shard is not None and shard[1] > 1 and not getattr(get_jk, "local_only", False):
+            # (`local_only`: diagnostic -- this rank's partial Fock matrices without the collective, so that one rank can time
+            #  its own share of the kernels while the others wait: tests/test_configs_gpu.py, bench.py per_rank)
             import torch.distributed as dist
             dist.all_reduce(fock)                 # the one collective of the path: sum of raw J/K over ranks
             vj = fock[0] if with_j else None
@@ -811,6 +813,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
                 h = n_dm // 2
                 vj = vj[:h] + vj[h:].transpose(1, 2)
             vj = vj + vj.transpose(1, 2)
+            if getattr(get_jk, "keep_internal", False):      # (bench.py's parity figure: shell blocks in the internal AO order)
+                state["stats"]["vj_internal"] = vj
             vj = layout.dm_to_mol(vj).reshape(out_shape)
         else:
             vj = 0
@@ -820,6 +824,8 @@ def generate_jk_kernel(basis_layout, cutoff_fp64=1e-13, cutoff_fp32=1e-13, shard
             else:
                 h = n_dm // 2
                 vk = vk[:h] + vk[h:].transpose(1, 2)
+            if getattr(get_jk, "keep_internal", False):
+                state["stats"]["vk_internal"] = vk
             vk = layout.dm_to_mol(vk).reshape(out_shape)
         else:
             vk = 0

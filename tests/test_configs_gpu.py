@@ -189,7 +189,22 @@ def _rank_worker(rank, world, port, q):
     n64 = g.quartet_counts()[0]
     if rank == 0:
         torch.save((vj.cpu(), vk.cpu()), os.path.join("/tmp", f"jqc_cfg5_{port}.pt"))
-    q.put((rank, n64, time.time() - t, [float(x) for x in jkmod.build_tile_plan.last_predicted_load]))
+    wall = time.time() - t
+    # MEASURED kernel time of this rank's share: the ranks take turns on the one device (no collective in a `local_only` call), class
+    # launches serialised on one stream and bracketed by HIP events, as in bench.py's roofline leg
+    g.local_only = True
+    g.set_streams(1)
+    kernel_ms = 0.0
+    for turn in range(world):
+        dist.barrier()
+        if turn == rank:
+            g.set_probe("all")
+            g(mol, dm, hermi=1)
+            torch.cuda.synchronize()
+            kernel_ms = float(sum(e0.elapsed_time(e1) for e0, e1 in g.stats.get("probe_events", [])))
+            g.set_probe(None)
+    dist.barrier()
+    q.put((rank, n64, wall, [float(x) for x in jkmod.build_tile_plan.last_predicted_load], kernel_ms))
     dist.destroy_process_group()
 
 
@@ -290,6 +305,10 @@ def test_config5_425_atoms_svp_one_rank_and_two_ranks():
     load = res[0][3]
     assert max(load) < 1.10 * (sum(load) / len(load)), load
     assert min(res[0][1], res[1][1]) > 0.25 * n_all
+    # ... and the MEASURED kernel time of the two shares (each rank alone on the device, serial launches, HIP events) agrees with it
+    kms = [r[4] for r in res]
+    print("config 5, two ranks: predicted load", [round(x, 1) for x in load], "measured kernel ms", [round(x, 1) for x in kms])
+    assert min(kms) > 0 and max(kms) < 1.15 * (sum(kms) / len(kms)), kms
 
 
 def _mol112(basis):

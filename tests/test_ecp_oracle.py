@@ -46,6 +46,24 @@ def test_parse_ecp_builds_pyscf_rows():
     assert m1._ecpbas[:, gecp.ANG_OF].tolist() == [-1, -1]
 
 
+def test_spin_orbit_rows_of_ecpbas_are_ignored():
+    """A PySCF molecule whose ECP carries spin-orbit terms (crenbl / crenbs) has extra ``_ecpbas`` rows with SO_TYPE_OF != 0;
+    the scalar potential must not see them (reference: /root/reference/jqc/backend/ecp.py:1313-1315 keeps SO_TYPE_OF == 0 only)."""
+    from joltqc_amd.backend import ecp as becp
+    from joltqc_amd.gto import ecp as gecp
+    mol = na2(ECP_TYPE2)
+    ref_ch = gecp.channels(mol)
+    ref_xyz, ref_loc, ref_terms = becp.ecp_arrays(mol)
+    so = mol._ecpbas[1].copy()                                # a P-channel row re-labelled as a spin-orbit term
+    so[gecp.SO_TYPE_OF] = 1
+    mol._ecpbas = np.vstack([mol._ecpbas[:2], so[None], mol._ecpbas[2:]]).astype(np.int32)
+    assert mol._ecpbas.shape == (7, 8)
+    ch = gecp.channels(mol)
+    assert {k: len(v) for k, v in ch.items()} == {k: len(v) for k, v in ref_ch.items()}
+    xyz, loc, terms = becp.ecp_arrays(mol)
+    assert np.array_equal(loc, ref_loc) and np.array_equal(terms, ref_terms) and np.array_equal(xyz, ref_xyz)
+
+
 def test_real_spherical_harmonic_table_is_orthonormal():
     """ylm_table (device input): int Y_lm Y_l'm' dOmega = delta, from the exact monomial integrals over the sphere."""
     from joltqc_amd.backend import ecp as becp

@@ -38,16 +38,33 @@ def env_for(defs, classes):
     return e
 
 
+def ok_file():
+    import hashlib
+    h = hashlib.md5((os.environ.get("JQC_EXTRA_DEFS", "") + "|" + os.environ.get("JQC_JK_ALGO", "")).encode()).hexdigest()[:12]
+    return os.path.join(ROOT, "joltqc_amd", "csrc", "kcache_dev", f"ok_{h}.json")
+
+
 def child_build(classes):
+    """Compile; the classes whose build exists (no LDS overflow, no static assertion) are recorded next to the code objects, and a
+    timing run of this configuration is restricted to them."""
     from joltqc_amd.backend import jk as router
-    bad = []
+    bad, ok = [], []
     for ang in classes:
+        good = True
         for small in (False, True):
             try:
-                router.gen_jk_kernel(ang, True, True, False, False, router.select_algo(ang, small=small), True)
+                want = router.select_algo(ang, small=small)
+                router.gen_jk_kernel(ang, True, True, False, False, want, True)
+                if os.environ.get("JQC_JK_ALGO") and router.resolved_algo(ang, True, True, False, False, want) != want:
+                    good = False                      # (the router fell back to a smaller form: not the configuration asked for)
             except RuntimeError as e:
-                bad.append((ang, str(e)[-200:]))
-    print("built", len(classes), "classes with", repr(os.environ.get("JQC_EXTRA_DEFS")), "failures:", bad, flush=True)
+                good = False
+                bad.append(("%d%d%d%d" % ang, str(e).strip().splitlines()[-1][-60:] if "static assertion" not in str(e) else "static_assert"))
+        if good:
+            ok.append("%d%d%d%d" % ang)
+    json.dump(ok, open(ok_file(), "w"))
+    print("built", len(ok), "of", len(classes), "classes with", repr(os.environ.get("JQC_EXTRA_DEFS")), os.environ.get("JQC_JK_ALGO", ""),
+          "failed:", " ".join(b[0] for b in bad), flush=True)
 
 
 def child_check(classes):
@@ -90,21 +107,36 @@ def child_check(classes):
 if __name__ == "__main__":
     cmd = sys.argv[1]
     if cmd in ("_build", "_check"):
-        cl = class_list(sys.argv[2])
+        cl = [tuple(int(ch) for ch in k) for k in sys.argv[2].split(",")]
         (child_build if cmd == "_build" else child_check)(cl)
         sys.exit(0)
     spec = sys.argv[2]
     cfgs = [(x.split("=", 1)[0], x.split("=", 1)[1]) for x in sys.argv[3:]]
     classes = class_list(spec)
+    spec = ",".join("%d%d%d%d" % a for a in classes)
     if cmd == "build":
-        procs = [subprocess.Popen([sys.executable, __file__, "_build", spec], env=env_for(d, classes)) for _, d in cfgs]
-        sys.exit(max(p.wait() for p in procs))
+        rc = 0
+        for lo in range(0, len(cfgs), 4):          # four configurations at a time (each child compiles serially)
+            procs = [subprocess.Popen([sys.executable, __file__, "_build", spec], env=env_for(d, classes)) for _, d in cfgs[lo:lo + 4]]
+            rc = max([rc] + [p.wait() for p in procs])
+        sys.exit(rc)
     wl = os.environ.get("JQC_AB_WORKLOAD", "0112-elongated-nitrogenous")
     out = {}
     for name, d in cfgs:
         env = env_for(d, classes)
-        r = subprocess.run([sys.executable, __file__, "_check", spec], env=env, capture_output=True, text=True)
-        chk = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-1500:]
+        okf = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import dev_ab; print(dev_ab.ok_file())" % os.path.dirname(os.path.abspath(__file__))],
+                             env=env, capture_output=True, text=True).stdout.strip()
+        if okf and os.path.exists(okf):                  # classes that built for this configuration (recorded by `build`)
+            good = set(json.load(open(okf)))
+            env["JQC_ONLY_CLASS"] = ",".join(k for k in env["JQC_ONLY_CLASS"].split(",") if k in good)
+            if not env["JQC_ONLY_CLASS"]:
+                out[name] = {"defs": d, "check": "no class built", "ms": {}, "sum_ms": 0.0}
+                continue
+        if os.environ.get("JQC_AB_NOCHECK"):             # timing sweep: the winners are checked in a second run
+            chk = "skipped"
+        else:
+            r = subprocess.run([sys.executable, __file__, "_check", spec], env=env, capture_output=True, text=True)
+            chk = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-1500:]
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "class_profile.py"), wl], env=env, capture_output=True, text=True)
         rows = {}
         for line in r.stdout.splitlines():

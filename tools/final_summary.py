@@ -45,6 +45,7 @@ for us, k, hw, mf, nq, fetch, write, atom, hit, miss in rows:
           f"{(fetch+write)/us/1e3:.1f},{atom:.4g},{hit/(hit+miss) if hit+miss else float('nan'):.3f}")
 # machine-readable copy for bench.py's roofline.traffic (profiles/*pmc_traffic*.json)
 json.dump({k: {"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "us_per_launch": us,
+               "quartets": (nq if nq == nq else None),
                "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction of MI355X_MICROARCH.md) and WRITE_SIZE, separate passes"}
            for us, k, hw, mf, nq, fetch, write, atom, hit, miss in rows if fetch == fetch and write == write},
           open(f"{root}/pmc_traffic.json", "w"), indent=1)

@@ -25,7 +25,7 @@ nwg = max(int(st[15]), 1)
 names = ["lookup", "bra stage", "Dij stage", "ket loads issue", "ket stage stores", "barrier1", "compute", "barrier2", "flush", "Jij flush+exit"]
 n64, _, per = g.quartet_counts()
 print(f"{name} class {cls}: workgroups {nwg}, quartets {n64}, quartets/WG {n64 / nwg:.1f}")
-tot = sum(int(x) for x in st[:14])
+tot = sum(int(x) for x in st[:15])
 from joltqc_amd.backend import jk as _router
 tile1q = (_router.select_algo(tuple(int(c) for c in cls)) & 0xf) == 2
 lanes = 0
@@ -35,8 +35,8 @@ if tile1q and int(st[11]):
     lanes = int(st[13]); st[13] = 0
     st[6] -= st[10] + st[11] + st[12]
 elif int(st[10]) + int(st[11]):
-    names += ["  (phase A)", "  (phase B)", "  (step barrier)", "  (contraction)"]
-    st[6] -= st[10] + st[11] + st[12] + st[13]      # compute = remainder outside the stamped inner phases
+    names += ["  (phase A)", "  (phase B)", "  (step barrier)", "  (owner red.+step head)" if int(st[14]) else "  (contraction)", "  (contraction arith.)"]
+    st[6] -= st[10] + st[11] + st[12] + st[13] + st[14]      # compute = remainder outside the stamped inner phases
 for k, nm in enumerate(names):
     print(f"  {nm:16s} {int(st[k]) / nwg:10.0f} cycles/WG  {100.0 * int(st[k]) / max(tot, 1):5.1f} %")
 print(f"  total            {tot / nwg:10.0f} cycles/WG")
