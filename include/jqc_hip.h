@@ -61,6 +61,12 @@ extern "C" {
 #define JQC_VARIANT_QCHUNK(code, index) (((code) << 25) | ((index) << 27)) /* quad builds of the 270-330-integral classes: the lane's third of
                                      * the integral block is evaluated in 2 / 3 / 5 chunks (code 1 / 2 / 3) over the Cartesian components of
                                      * shell `index` (0..3 = i, j, k, l; not the split p shell), recurrences and roots redone per chunk */
+#define JQC_VARIANT_HB (1 << 29)   /* row-lane mode, "h form" (needs JQC_VARIANT_ORED, excludes JQC_VARIANT_CJR): phase A runs the transfer
+                                    * AND the bra horizontal recurrence once per (quartet, root, axis) and leaves h[i][j][c] in LDS; a
+                                    * phase-B lane = (bra component i, group of j components) reads one row per (axis, j component), runs
+                                    * the ket recurrence and multiplies -- the bra recurrence is no longer redone per lane, root and chunk */
+#define JQC_VARIANT_HEJ(code) ((code) << 25) /* h form: j components per lane = the largest divisor of nf_j that is <= 1 (code 0), 2 (1),
+                                    * 3 (2), 6 (3); shares its bits with JQC_VARIANT_QCHUNK (quad builds are lane-per-quartet builds) */
 #define JQC_VARIANT_MIXED (1 << 21) /* FP64 lane-per-quartet build with BOTH precision windows in one launch: quartets with an
                                       estimate above cut_hi in FP64, those in (cut_lo, cut_hi] in FP32, two per lane as packed
                                       2-vectors (v_pk_fma_f32); one staging / screening / flush per tile pair (replaces the reference's

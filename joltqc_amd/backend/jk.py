@@ -11,7 +11,8 @@ from functools import lru_cache
 
 from . import lib as _lib
 
-_SCHEME = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "gfx950_scheme.json")
+# (JQC_SCHEME_JSON: another table for A/B runs, e.g. the previous round's)
+_SCHEME = os.environ.get("JQC_SCHEME_JSON") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "gfx950_scheme.json")
 
 
 @lru_cache(maxsize=1)
@@ -69,6 +70,16 @@ VARIANT_QUAD = 1 << 24         # lane-per-quartet mode with one quartet per DPP 
 VARIANT_QCHUNK = lambda code, index: (code << 25) | (index << 27)     # quad builds: 2 / 3 / 5 chunks (code 1 / 2 / 3) over the components of shell `index`
 QCHUNKS = (1, 2, 3, 5)
 VARIANT_MIXED = 1 << 21        # both precision windows in one launch of an FP64 lane-per-quartet build (FP32 phase packed)
+VARIANT_HB = 1 << 29           # row-lane mode, h form: bra horizontal recurrence in phase A, lane = (bra component i, group of j components)
+VARIANT_HEJ = lambda code: code << 25      # h form: j components per lane capped at HEJ_CAPS[code] (bits shared with the quad chunk code)
+HEJ_CAPS = (1, 2, 3, 6)
+
+
+def hb_ej(ang, v):
+    """j components per lane of the h-form variant ``v``: the largest divisor of nf_j that is <= the cap (jk_tile.hip pick_hej)."""
+    nfj = (ang[1] + 1) * (ang[1] + 2) // 2
+    cap = HEJ_CAPS[(v >> 25) & 3]
+    return max(n for n in range(1, nfj + 1) if nfj % n == 0 and n <= cap)
 
 
 def supports_mixed(ang, v):
@@ -102,6 +113,8 @@ def mixed_fused(ang, v):
 def lanes_per_quartet(ang, v):
     """Row lanes T of one quartet under variant ``v`` (j components in registers: nf_i, otherwise nf_i * nf_j)."""
     nf = lambda l: (l + 1) * (l + 2) // 2
+    if v & VARIANT_HB:
+        return nf(ang[0]) * (nf(ang[1]) // hb_ej(ang, v))
     return nf(ang[0]) if (v & 0x800) else nf(ang[0]) * nf(ang[1])
 
 
@@ -134,13 +147,25 @@ def forced_variant(ang, v):
         xs = 3 if ang[3] == 1 else 2 if ang[2] == 1 else 1 if ang[1] == 1 else 0          # the split p shell (jk_tile.hip XS)
         if code and (qy == xs or nf(ang[qy]) % QCHUNKS[code]):
             v &= ~(0xf << 25)                         # chunks must divide the component count of another shell
+    elif v & VARIANT_HB:
+        # h form: row-lane builds with the owner reduction and a quartet inside one wave; where nf_i * nf_j / EJ exceeds 64 lanes the
+        # j-group is widened, and the form is dropped where even that does not fit (or the class is not a row-lane class here)
+        v &= ~(0x3 << 27)
+        if (v & 0xf) != _lib.ALGO_TILE:
+            v &= ~(VARIANT_HB | (0xf << 25))
+        else:
+            v = (v | VARIANT_ORED) & ~0x800
+            while lanes_per_quartet(ang, v) > 64 and ((v >> 25) & 3) < 3:
+                v += 1 << 25
+            if lanes_per_quartet(ang, v) > 64:
+                v &= ~(VARIANT_HB | (0xf << 25))
     else:
         v &= ~(0xf << 25)
     if (v & 0xf) != _lib.ALGO_TILE1Q:
         v &= ~(0xf000 | VARIANT_MIXED)                # several ket pairs per iteration, strided queue, row-ordered contraction,
                                                       # fused precision phases: lane-per-quartet mode only
     nf = lambda l: (l + 1) * (l + 2) // 2
-    if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or nf(ang[0]) * nf(ang[1]) > 64):
+    if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or (lanes_per_quartet(ang, v) if v & VARIANT_HB else nf(ang[0]) * nf(ang[1])) > 64):
         v &= ~0x400
     # a fused mixed-precision build reads its two cutoffs differently from every other build (FP64 above cut_hi, FP32 below): it is
     # only ever reached through mixed_variant() on the fused launch path of pyscf/jk.py, never selected as a class's kernel
@@ -187,7 +212,7 @@ def kernel_key(ang, do_j, do_k, rys_lr, fp32, algo):
                                                 ".".join(str(int(w)) for w in TILE_WIDTHS))
 
 
-_MANIFEST = os.path.join(os.path.dirname(_SCHEME), "verified_kernels.json")
+_MANIFEST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "verified_kernels.json")
 
 
 @lru_cache(maxsize=1)
@@ -296,7 +321,7 @@ def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None
                 # two matrices do not fit even with one ket pair per iteration: one matrix per pass, with the ket pairs per
                 # iteration the variant was tuned for (not the 1 the steps above ended on)
                 algo = (algo & ~VARIANT_NDM2 & ~0x3000) | (want & 0x3000)
-            elif (algo & 0xf) != _lib.ALGO_TILE or (algo & 0xc00):
+            elif (algo & 0xf) != _lib.ALGO_TILE or (algo & 0xc00) or (algo & VARIANT_HB):
                 algo = _lib.ALGO_TILE | (algo & 0x1f0)
             else:
                 raise

@@ -546,7 +546,7 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
     for (const char* f : {"jk_common.h", "jk_axis.h"}) h0 = mix(h0, read_file(g_src_dir + "/" + f));
     if (const char* extra = getenv("JQC_EXTRA_DEFS")) h0 = mix(h0, extra);
     // (bump when the build logic of jqc_gen_jk_kernel changes: MINW rebuild loop, ECAP codes, KARG_RELOAD choice, variant bits)
-    h0 = mix(h0, "build-policy-r4:karg-reload-iff-scratch,ored,paroot,ndm2,family-tags,mixed,rsplit");
+    h0 = mix(h0, "build-policy-r6:karg-reload-iff-scratch,ored,paroot,ndm2,family-tags,mixed,rsplit,quad,qchunk,hb,hej");
     // compiler version and option set: register allocation decides which builds pass the gates, so code
     // objects of another hiprtc are other builds -- not reused from the cache, not covered by the verified manifest
     {
@@ -608,8 +608,13 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     const int v_ecap = (algo_variant >> 16) & 3;
     const int v_ored = (algo_variant >> 18) & 1, v_paroot = (algo_variant >> 19) & 1, v_ndm2 = (algo_variant >> 20) & 1;
     const int v_mixed = (algo_variant >> 21) & 1, v_rsplit = (algo_variant >> 22) & 3;
-    const int v_quad = (algo_variant >> 24) & 1, v_qnch = (algo_variant >> 25) & 3, v_qy = (algo_variant >> 27) & 3;
+    // h form of the row-lane kernels (bit 29); its j-components-per-lane code shares bits 25-26 with the quad chunk code (the two
+    // forms exclude each other: quad = lane-per-quartet builds, h form = row-lane builds)
+    const int v_hb = (algo_variant >> 29) & 1, v_hej = v_hb ? (algo_variant >> 25) & 3 : 0;
+    const int v_quad = (algo_variant >> 24) & 1, v_qnch = v_hb ? 0 : (algo_variant >> 25) & 3, v_qy = v_hb ? 0 : (algo_variant >> 27) & 3;
     if (v_qnch && !v_quad) return fail(-1, "JQC_VARIANT_QCHUNK: quad builds only");
+    if (v_hb && ((algo != JQC_ALGO_TILE && algo != JQC_ALGO_TILE512) || !((algo_variant >> 18) & 1) || ((algo_variant >> 11) & 1) || v_quad))
+        return fail(-1, "JQC_VARIANT_HB: row-lane builds with the owner reduction (JQC_VARIANT_ORED), without JQC_VARIANT_CJR");
     if (v_quad && (algo != JQC_ALGO_TILE1Q || v_mixed || (li + lj + lk + ll) / 2 + 1 > 4 || (li != 1 && lj != 1 && lk != 1 && ll != 1)))
         return fail(-1, "JQC_VARIANT_QUAD: lane-per-quartet builds of classes with a p shell and at most four Rys roots");
     if (v_mixed && (algo != JQC_ALGO_TILE1Q || fp32 || v_ndm2))
@@ -654,6 +659,11 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
         if (v_ndm2) d.push_back("-DNDM=2");
         if (v_mixed) d.push_back("-DMIXED=1");
         if (v_rsplit) d.push_back("-DRSPLIT=" + std::to_string(v_rsplit + 1));
+        if (v_hb) {
+            static const int hej_cap[4] = {1, 2, 3, 6};
+            d.push_back("-DHB=1");
+            d.push_back("-DHEJ=" + std::to_string(hej_cap[v_hej]));
+        }
         if (v_quad) d.push_back("-DQUAD=1");
         if (v_qnch) {
             static const int nch[4] = {1, 2, 3, 5};

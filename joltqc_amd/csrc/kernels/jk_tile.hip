@@ -24,6 +24,10 @@
 //              (compile-time indices only: no scratch, no LDS traffic in the inner product loop).
 //   The six contractions then go to the LDS Fock tiles; J_kl, K_jk, K_jl are first summed in registers
 //   across consecutive quartets that share the destination block.
+//   HB=1 ("h form", round 6): phase A also runs the bra horizontal recurrence, once per (quartet, root, axis), and leaves
+//   h[root][axis][i][j][c] in LDS; a phase-B lane = (bra component i, group of j components) reads one row per (axis,
+//   j component), runs only the ket recurrence and multiplies -- the other row-lane forms redo the bra recurrence in every
+//   lane, root and integral chunk (hardware / model flop 1.7-2.6 in the round-5 counters).
 //
 // Mathematics (what is computed) follows the reference kernels
 //   /root/reference/jqc/backend/jk/1q1t.cu:86-94 (symmetry factors), :174-242 (primitive prefactors,
@@ -117,6 +121,9 @@ constexpr int NQ = TSI * TSJ * TSK * TSL;
                     // quartet with all lanes of the instruction on different addresses.  The scratch aliases the TRR array,
                     // which is dead during the contraction.
 #endif
+#ifndef ORED_HOIST
+#define ORED_HOIST 1  // owner reduction: the owner's quartets are decoded once per step, the reads of a pass are issued together, sums pairwise
+#endif
 #ifndef RSPLIT
 #define RSPLIT 1    // row-lane mode: the Rys roots of a primitive combination go through phase A / phase B in RSPLIT groups, so the TRR
                     // array holds NROOTS / RSPLIT roots per quartet: half the LDS of the largest array of these kernels (2121: 61 of
@@ -126,8 +133,28 @@ constexpr int NQ = TSI * TSJ * TSK * TSL;
 #define PAROOT 0    // row-lane mode: a phase-A job = (quartet, root) and runs the transfer recurrence of all three axes, so the
                     // Rys root and the primitive prefactors are evaluated once instead of three times
 #endif
-constexpr int EJ = CJR ? NFJ : 1;                    // bra j components held per lane
-constexpr int T = CJR ? NFI : NFI * NFJ;
+#ifndef HB
+#define HB 0        // row-lane mode, "h form": phase A runs the transfer recurrence AND the bra horizontal recurrence, once per (quartet,
+                    // root, axis), and leaves h[root][axis][i][j][c] (i <= LI, j <= LJ, c <= LKL) in LDS; a phase-B lane then reads ONE row
+                    // (LKL + 1 reals) per (axis, j component), runs only the cheap ket recurrence and multiplies.  The plain row-lane
+                    // forms redo the bra recurrence in every lane, root and integral chunk (hardware / model flop 1.7-2.6).
+                    // Lane = (bra component ci, j-group jg): HEJ consecutive j components per lane, NJG = NFJ / HEJ lanes per ci, so the
+                    // integral block of a lane is sized by HEJ instead of by chunks over k (no second pass through phase A).
+#endif
+#ifndef HEJ
+#define HEJ 1       // HB: bra j components per lane = the largest divisor of NFJ that is <= HEJ
+#endif
+constexpr int pick_hej()
+{
+    int best = 1;
+    for (int n = 1; n <= NFJ && n <= HEJ; n++)
+        if (NFJ % n == 0) best = n;
+    return best;
+}
+constexpr int EJ = HB ? pick_hej() : CJR ? NFJ : 1;  // bra j components held per lane
+constexpr int NJG = NFJ / EJ;                        // lanes per bra component ci
+constexpr int T = NFI * NJG;
+static_assert(!HB || !CJR, "HB: CJR is its HEJ = NFJ case");
 #ifndef TBLOCK
 #define TBLOCK 256   // threads per workgroup (512: two waves per SIMD share one set of LDS tiles; row-lane mode only)
 #endif
@@ -172,7 +199,7 @@ constexpr int NCH = pick_nch();
 constexpr int CW = NFK / NCH;
 constexpr int E = EJ * CW * NFL;                     // integrals per lane and chunk: e = (cj * CW + kk) * NFL + cl
 constexpr int WI = TSI * NFI, WJ = TSJ * NFJ, WK = TSK * NFK, WL = TSL * NFL;
-constexpr int NT2 = (LIJ + 1) * (LKL + 1);
+constexpr int NT2 = HB ? (LI + 1) * (LJ + 1) * (LKL + 1) : (LIJ + 1) * (LKL + 1);    // reals per (root, axis) in the LDS array
 constexpr int NRH = (NROOTS + RSPLIT - 1) / RSPLIT;                       // roots per phase-A / phase-B pass
 constexpr int NJOB = G * 3 * NRH;                                         // phase-A jobs per pass
 // The TRR array is single-buffered.  A double-buffered schedule (phase A of the next primitive combination issued before
@@ -191,7 +218,7 @@ constexpr int NBUF = (TRR_DOUBLE_BUFFER && !WSYNC && !USE_ORED && 2 * G * TRR_SL
 // owner reduction (ORED): values per lane and step, scratch rows of RSTR doubles (odd: the owner lanes read column-wise)
 // rows: J_kl [CW * NFL], K_jk [EJ * CW], K_jl [EJ * NFL]; lane = (ci, cj) form in addition K_ik [CW], K_il [NFL] (summed over cj)
 constexpr int NE0 = DO_J ? CW * NFL : 0, NE1 = DO_K ? EJ * CW : 0, NE2 = DO_K ? EJ * NFL : 0;
-constexpr int NE3 = (DO_K && !CJR) ? CW : 0, NE4 = (DO_K && !CJR) ? NFL : 0, NPART = NE0 + NE1 + NE2 + NE3 + NE4;
+constexpr int NE3 = (DO_K && !CJR && !(HB && NJG == 1)) ? CW : 0, NE4 = (DO_K && !CJR && !(HB && NJG == 1)) ? NFL : 0, NPART = NE0 + NE1 + NE2 + NE3 + NE4;
 constexpr int RSTR = 66;
 constexpr int RDBL = 8 / (int)sizeof(real);                                 // reals per double
 constexpr int RG_MIN = NPART < 16 ? NPART : 16;                              // rows the scratch of a wave holds at least
@@ -213,6 +240,7 @@ __device__ __forceinline__ int trr_off(const int sl)
 static_assert(!WSYNC || (T <= 64 && !TILE_1Q), "WSYNC needs a quartet to fit one wave");
 static_assert(RSPLIT == 1 || (!TILE_1Q && NBUF == 1), "RSPLIT: row-lane mode, single-buffered TRR array");
 static_assert(!CJR || !TILE_1Q, "CJR is a variant of the row-lane mode");
+static_assert(!HB || (!TILE_1Q && ORED && T <= 64), "HB: row-lane builds with the owner reduction, a quartet inside one wave");
 static_assert(NDM == 1 || NDM == 2, "density matrices per integral evaluation");
 static_assert(NDM == 1 || ((TILE_1Q || USE_ORED) && !CTWO_ && !CORD_ && !STAGE_ALL_), "NDM > 1: lane-per-quartet or owner-reduction builds");
 #if WSYNC
@@ -417,6 +445,27 @@ __device__ __forceinline__ real quad_bcast(const real v, const int r)
     case 1: return dpp_quad<0x55>(v);
     case 2: return dpp_quad<0xaa>(v);
     default: return dpp_quad<0xff>(v);
+    }
+}
+#endif
+
+#if HB
+// bra horizontal recurrence of one axis on the transfer-recurrence array tt[a][c] (a <= LIJ), written to LDS as h[i][j][c]:
+// (i, j + 1) = (i + 1, j) - (Rj - Ri) (i, j)   (reference jk/1q1t.cu:336-360)
+__device__ __forceinline__ void bra_hrr_store(real (&tt)[LIJ + 1][LKL + 1], const real rij, real* __restrict__ dst)
+{
+#pragma unroll
+    for (int j = 0; j <= LJ; j++) {
+#pragma unroll
+        for (int i = 0; i <= LI; i++)
+#pragma unroll
+            for (int cc = 0; cc <= LKL; cc++) dst[(i * (LJ + 1) + j) * (LKL + 1) + cc] = tt[i][cc];
+        if (j < LJ) {
+#pragma unroll
+            for (int a = 0; a < LIJ - j; a++)
+#pragma unroll
+                for (int cc = 0; cc <= LKL; cc++) tt[a][cc] = tt[a + 1][cc] - rij * tt[a][cc];
+        }
     }
 }
 #endif
@@ -703,11 +752,24 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     const bool lane_on = WMAP ? qslot < GW : slot < G;
 #if CJR
     const int ci = t, cj = 0;
+#elif HB
+    const int ci = t / NJG, jg = t - ci * NJG, cj = jg * EJ;       // cj: the lane's first j component
 #else
     const int ci = t / NFJ, cj = t - ci * NFJ;
 #endif
     const int ibra[3] = {TI.x[ci], TI.y[ci], TI.z[ci]};
     const int jbra[3] = {TJ.x[cj], TJ.y[cj], TJ.z[cj]};
+#if HB
+    // row of h[i][j][.] the lane reads for its j component e on each axis (NJG > 1: the j powers of a lane are run-time values)
+    int hrow[EJ][3];
+#pragma unroll
+    for (int e = 0; e < EJ; e++) {
+        const int cje = cj + e;
+        hrow[e][0] = (ibra[0] * (LJ + 1) + TJ.x[cje]) * (LKL + 1);
+        hrow[e][1] = (ibra[1] * (LJ + 1) + TJ.y[cje]) * (LKL + 1);
+        hrow[e][2] = (ibra[2] * (LJ + 1) + TJ.z[cje]) * (LKL + 1);
+    }
+#endif
 #endif
     const size_t nao2 = (size_t)nao * nao;
     unsigned nq_done = 0;
@@ -1916,10 +1978,14 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                             }
                         }
                         real* __restrict__ dst = buf + trr_off(sa) + (rloc * 3 + ax) * NT2;
+#if HB
+                        bra_hrr_store(tt, rijv[ax], dst);
+#else
 #pragma unroll
                         for (int q = 0; q <= LIJ; q++)
 #pragma unroll
                             for (int cc = 0; cc <= LKL; cc++) dst[q * (LKL + 1) + cc] = tt[q][cc];
+#endif
                     }
                 }
 #else
@@ -1995,10 +2061,14 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         }
                     }
                     real* __restrict__ dst = buf + trr_off(sa) + (rloc * 3 + ax) * NT2;
+#if HB
+                    bra_hrr_store(tt, rij_a, dst);
+#else
 #pragma unroll
                     for (int q = 0; q <= LIJ; q++)
 #pragma unroll
                         for (int cc = 0; cc <= LKL; cc++) dst[q * (LKL + 1) + cc] = tt[q][cc];
+#endif
                 }
 #endif  // PAROOT
             };
@@ -2037,7 +2107,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     // bra HRR as a weighted sum over TRR rows: g(i,j) = sum_m C(j,m) (Ri-Rj)^(j-m) t[i+m]
                     real wb[3][LJ + 1];
 #pragma unroll
-                    for (int ax = 0; ax < 3; ax++) {
+                    for (int ax = 0; ax < 3 && !HB && !CJR; ax++) {
                         const int ja = jbra[ax];
                         const real ab = -rij[ax];
                         real pw = 1;      // ab^(ja-m), built downwards from m = ja
@@ -2120,6 +2190,72 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                                                               gk[1][TJ.y[oj]][TK.y[ck]][TL.y[cl]] *
                                                                               gk[2][TJ.z[oj]][TK.z[ck]][TL.z[cl]];
                                         }
+                            }
+#elif HB
+                                if (NJG == 1) {
+                                    // every j component in the lane: rows (i_ax, j = 0..LJ) of each axis, ket HRR, gk[axis][j][k][l]
+                                    real gk[3][LJ + 1][LK + 1][LL + 1];
+#pragma unroll
+                                    for (int ax = 0; ax < 3; ax++) {
+                                        const real* __restrict__ tp = myT + (r * 3 + ax) * NT2 + ibra[ax] * ((LJ + 1) * (LKL + 1));
+#pragma unroll
+                                        for (int j = 0; j <= LJ; j++) {
+                                            real w[LKL + 1];
+#pragma unroll
+                                            for (int cc = 0; cc <= LKL; cc++) w[cc] = tp[j * (LKL + 1) + cc];
+#pragma unroll
+                                            for (int l = 0; l <= LL; l++) {
+#pragma unroll
+                                                for (int k = 0; k <= LK; k++) gk[ax][j][k][l] = w[k];
+                                                if (l < LL) {
+#pragma unroll
+                                                    for (int cc = 0; cc < LKL - l; cc++) w[cc] = w[cc + 1] - rkl[ax] * w[cc];
+                                                }
+                                            }
+                                        }
+                                    }
+#pragma unroll
+                                    for (int oj = 0; oj < NFJ; oj++)
+#pragma unroll
+                                        for (int kk = 0; kk < CW; kk++)
+#pragma unroll
+                                            for (int cl = 0; cl < NFL; cl++) {
+                                                const int ck = CH * CW + kk;
+                                                acc[(oj * CW + kk) * NFL + cl] += gk[0][TJ.x[oj]][TK.x[ck]][TL.x[cl]] *
+                                                                                  gk[1][TJ.y[oj]][TK.y[ck]][TL.y[cl]] *
+                                                                                  gk[2][TJ.z[oj]][TK.z[ck]][TL.z[cl]];
+                                            }
+                                } else {
+                                    // lane = (ci, j-group): per j component one row per axis (run-time row offsets), ket HRR, products
+#pragma unroll
+                                    for (int e = 0; e < EJ; e++) {
+                                        real gk[3][LK + 1][LL + 1];
+#pragma unroll
+                                        for (int ax = 0; ax < 3; ax++) {
+                                            const real* __restrict__ tp = myT + (r * 3 + ax) * NT2 + hrow[e][ax];
+                                            real w[LKL + 1];
+#pragma unroll
+                                            for (int cc = 0; cc <= LKL; cc++) w[cc] = tp[cc];
+#pragma unroll
+                                            for (int l = 0; l <= LL; l++) {
+#pragma unroll
+                                                for (int k = 0; k <= LK; k++) gk[ax][k][l] = w[k];
+                                                if (l < LL) {
+#pragma unroll
+                                                    for (int cc = 0; cc < LKL - l; cc++) w[cc] = w[cc + 1] - rkl[ax] * w[cc];
+                                                }
+                                            }
+                                        }
+#pragma unroll
+                                        for (int kk = 0; kk < CW; kk++)
+#pragma unroll
+                                            for (int cl = 0; cl < NFL; cl++) {
+                                                const int ck = CH * CW + kk;
+                                                acc[(e * CW + kk) * NFL + cl] += gk[0][TK.x[ck]][TL.x[cl]] * gk[1][TK.y[ck]][TL.y[cl]] *
+                                                                                 gk[2][TK.z[ck]][TL.z[cl]];
+                                            }
+                                    }
+                                }
                             }
 #else
                                 real gk[3][LK + 1][LL + 1];
@@ -2284,6 +2420,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #endif
                     }
 #if ORED
+                    STAMP(14);
                     // ---- owner reduction of the values summed over the lanes of a quartet (J_kl, K_jk, K_jl of this step).
                     //      Scratch of this wave: red[row][lane] inside its own part of the TRR array (dead until the next
                     //      phase A).  Row r of a pass is summed by NH owner lanes, each over the quartets qs = h, h + NH, ...
@@ -2291,6 +2428,64 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         double* __restrict__ red = (double*)(sT + wave_u * WREG);
                         const int ox = lane % RG, oh = lane / RG;
                         const double* __restrict__ row = red + ox * RSTR + oh * T;
+#if ORED_HOIST
+                        // the owner's quartets and their destination blocks do not change from pass to pass: decoded once per step
+                        constexpr int KN = (GW + NH - 1) / NH;
+                        bool okk[KN];
+                        int o0[KN], o1[KN], o2[KN];
+#pragma unroll
+                        for (int k = 0; k < KN; k++) {
+                            const int qs = oh + k * NH;
+                            const int qo = (wave * GW + qs) * per + step;
+                            okk[k] = oh < NH && qs < GW && qo < nact;
+                            const int qd2 = s_act[okk[k] ? qo : 0];
+                            const int a2 = qd2 % TSI, b2 = (qd2 / TSI) % TSJ, d2 = (qd2 / (TSI * TSJ)) % TSL;
+                            const int c2 = QC(qd2 / (TSI * TSJ * TSL), a2, b2, d2);
+                            o0[k] = (d2 * NFL) * WK + c2 * NFK;
+                            o1[k] = (b2 * NFJ) * WK + c2 * NFK;
+                            o2[k] = (b2 * NFJ) * WL + d2 * NFL;
+                        }
+#pragma unroll
+                        for (int ps = 0; ps < NPASS; ps++) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int r = 0; r < RG; r++) {
+                                const int e = ps * RG + r;                  // (compile-time)
+                                if (e < NPART)
+                                    red[r * RSTR + lane] = e < NE0 ? jkl_acc[e < NE0 ? e : 0]
+                                                         : e < NE0 + NE1 ? kjk_acc[(e >= NE0 && e < NE0 + NE1) ? e - NE0 : 0]
+                                                                         : kjl_acc[e >= NE0 + NE1 ? e - NE0 - NE1 : 0];
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const int e = ps * RG + ox;
+                            int blk = 2, off;
+                            {
+                                const int e1 = e - NE0, e2 = e - NE0 - NE1;
+                                off = (e2 / NFL) * WL + e2 % NFL;                                  // K_jl[oj][cl]
+                                if (e < NE0 + NE1) { blk = 1; off = (e1 / CW) * WK + CH * CW + e1 % CW; }     // K_jk[oj][kk]
+                                if (e < NE0) { blk = 0; off = (e % NFL) * WK + CH * CW + e / NFL; }           // J_kl[cl][kk]  (e = kk * NFL + cl)
+                            }
+                            double* const base = blk == 0 ? sJkl : blk == 1 ? sKjk : sKjl;
+                            // every read of the pass first (one LDS round trip for all the owner's quartets), pairwise sums, atomics last
+                            double v[KN][T];
+#pragma unroll
+                            for (int k = 0; k < KN; k++)
+#pragma unroll
+                                for (int u = 0; u < T; u++) v[k][u] = row[(oh + k * NH < GW ? k * NH * T : 0) + u];
+#pragma unroll
+                            for (int k = 0; k < KN; k++) {
+#pragma unroll
+                                for (int w = 1; w < T; w *= 2)
+#pragma unroll
+                                    for (int u = 0; u + w < T; u += 2 * w) v[k][u] += v[k][u + w];
+                            }
+#pragma unroll
+                            for (int k = 0; k < KN; k++)
+                                if (okk[k] && e < NPART) lds_add(base + (blk == 0 ? o0[k] : blk == 1 ? o1[k] : o2[k]) + off, v[k][0]);
+                        }
+#else
 #pragma unroll
                         for (int ps = 0; ps < NPASS; ps++) {
                             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2335,6 +2530,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                 }
                             }
                         }
+#endif
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -2371,10 +2567,65 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma unroll
                         for (int e = 0; e < CW * NFL; e++) jkl_acc[e] = 0;
 #pragma unroll
-                        for (int kk = 0; kk < CW; kk++) { kjk_acc[kk] = 0; s_ik[kk] = 0; }
+                        for (int kk = 0; kk < EJ * CW; kk++) kjk_acc[kk] = 0;
 #pragma unroll
-                        for (int cl = 0; cl < NFL; cl++) { kjl_acc[cl] = 0; kil[cl] = 0; }
+                        for (int cl = 0; cl < EJ * NFL; cl++) kjl_acc[cl] = 0;
+#pragma unroll
+                        for (int kk = 0; kk < CW; kk++) s_ik[kk] = 0;
+#pragma unroll
+                        for (int cl = 0; cl < NFL; cl++) kil[cl] = 0;
                     }
+#if HB
+                    if (on) {
+                        // lane = (ci, j-group), registers = (e, k, l): J_ij is complete in the lane; K_ik / K_il are sums over the lanes of
+                        // one ci (complete when NJG == 1), J_kl / K_jk / K_jl over the lanes of the quartet / of one j-group
+                        real s_ije[EJ];
+#pragma unroll
+                        for (int e = 0; e < EJ; e++) {
+                            real sj = 0;
+#if DO_J
+                            const real dij = sDij[(jA + e) * WI + iA];
+#endif
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++) {
+#if DO_K
+                                const real djk = sDjk[(jA + e) * WK + kb + kk], dik = sDik[iA * WK + kb + kk];
+                                real s_jk = 0;
+#endif
+#pragma unroll
+                                for (int cl = 0; cl < NFL; cl++) {
+                                    const real v = acc[(e * CW + kk) * NFL + cl];
+#if DO_J
+                                    sj += v * sDkl[(lbs + cl) * WK + kb + kk];
+                                    jkl_acc[kk * NFL + cl] += (double)(v * dij);
+#endif
+#if DO_K
+                                    s_ik[kk] += v * sDjl[(jA + e) * WL + lbs + cl];
+                                    kil[cl] += v * djk;
+                                    s_jk += v * sDil[iA * WL + lbs + cl];
+                                    kjl_acc[e * NFL + cl] += (double)(v * dik);
+#endif
+                                }
+#if DO_K
+                                kjk_acc[e * CW + kk] += (double)s_jk;
+#endif
+                            }
+                            s_ije[e] = sj;
+                        }
+#if DO_J
+#pragma unroll
+                        for (int e = 0; e < EJ; e++) lds_add(&sJij[(jA + e) * WI + iA], (double)s_ije[e]);
+#endif
+#if DO_K
+                        if (NJG == 1) {
+#pragma unroll
+                            for (int kk = 0; kk < CW; kk++) lds_add(&sKik[iA * WK + kb + kk], (double)s_ik[kk]);
+#pragma unroll
+                            for (int cl = 0; cl < NFL; cl++) lds_add(&sKil[iA * WL + lbs + cl], (double)kil[cl]);
+                        }
+#endif
+                    }
+#else
                     if (on) {
 #if DO_J
                         {
@@ -2438,13 +2689,133 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         }
 #endif
                     }
+#endif  // HB
+                    STAMP(14);
                     if (USE_ORED) {
-                        // ---- owner reduction, lane = (ci, cj) form: every output but J_ij is a sum over lanes of the quartet --
+                        // ---- owner reduction, lane = (ci, cj) form (HB: lane = (ci, j-group), NJG groups of EJ components): every output but J_ij is a sum over lanes of the quartet --
                         //      J_kl over all T lanes (type A), K_jk / K_jl over the NFI lanes of one cj (type B), K_ik / K_il over the
                         //      NFJ lanes of one ci (type C).  Same scratch as above: red[row][lane] of this wave.
                         constexpr int rg = RG > 0 ? RG : 1;
                         constexpr int OB = NE0, OC = NE0 + NE1 + NE2;
                         double* __restrict__ red = (double*)(sT + wave_u * WREG);
+#if ORED_HOIST
+                        // Owner lanes are tied to ONE quartet slot of the wave (lane % GW) for the whole step: its destination blocks are decoded
+                        // once; lane / GW enumerates the (row, group) sums of a pass.  Per pass: every read first, pairwise sums, atomics last.
+                        constexpr int gw = GW > 0 ? GW : 1;
+                        constexpr int NLQ = 64 / gw;                      // owner lanes per quartet slot
+                        const int oq = lane % gw, om = lane / gw;
+                        const int qo_ = (wave * gw + oq) * per + step;
+                        const bool oq_ok = om < NLQ && qo_ < nact;
+                        int bJkl, bKjk, bKjl, bKik, bKil;
+                        {
+                            const int qd2 = s_act[oq_ok ? qo_ : 0];
+                            const int a2 = qd2 % TSI, b2 = (qd2 / TSI) % TSJ, d2 = (qd2 / (TSI * TSJ)) % TSL;
+                            const int c2 = QC(qd2 / (TSI * TSJ * TSL), a2, b2, d2);
+                            bJkl = (d2 * NFL) * WK + c2 * NFK + CH * CW;
+                            bKjk = (b2 * NFJ) * WK + c2 * NFK + CH * CW;
+                            bKjl = (b2 * NFJ) * WL + d2 * NFL;
+                            bKik = (a2 * NFI) * WK + c2 * NFK + CH * CW;
+                            bKil = (a2 * NFI) * WL + d2 * NFL;
+                        }
+                        const double* __restrict__ qsrc = red + oq * T;
+#pragma unroll
+                        for (int ps = 0; ps < NPASS; ps++) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int r = 0; r < rg; r++) {
+                                const int e = ps * rg + r;                  // (compile-time)
+                                if (e < NPART) {
+                                    double val;
+                                    if (e < OB) val = jkl_acc[e < OB ? e : 0];
+                                    else if (e < OB + NE1) val = kjk_acc[(e >= OB && e < OB + NE1) ? e - OB : 0];
+                                    else if (e < OC) val = kjl_acc[(e >= OB + NE1 && e < OC) ? e - OB - NE1 : 0];
+                                    else if (e < OC + NE3) val = (double)s_ik[(e >= OC && e < OC + NE3) ? e - OC : 0];
+                                    else val = (double)kil[e >= OC + NE3 ? e - OC - NE3 : 0];
+                                    red[r * RSTR + lane] = val;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            constexpr int p_lo = 0;                          // (rows of a pass start at scratch row 0)
+                            const int g_lo = ps * rg, g_hi = (ps * rg + rg < NPART) ? ps * rg + rg : NPART;
+                            // rows of this pass by type (compile-time bounds)
+                            const int a_lo = g_lo, a_hi = g_hi < OB ? g_hi : OB, na = a_hi > a_lo ? a_hi - a_lo : 0;
+                            const int b_lo = g_lo > OB ? g_lo : OB, b_hi = g_hi < OC ? g_hi : OC, nb = b_hi > b_lo ? b_hi - b_lo : 0;
+                            const int c_lo = g_lo > OC ? g_lo : OC, c_hi = g_hi, nc = c_hi > c_lo ? c_hi - c_lo : 0;
+                            constexpr int KA = (rg + NLQ - 1) / NLQ, KB = (rg * NJG + NLQ - 1) / NLQ, KC = (rg * NFI + NLQ - 1) / NLQ;
+                            double va[KA][T], vb[KB][NFI], vc[KC][NJG];
+                            // ---- reads
+#pragma unroll
+                            for (int k = 0; k < KA; k++) {
+                                if (k * NLQ >= na) break;
+                                const int m = om + k * NLQ, rr = m < na ? m : 0;
+                                const double* __restrict__ src = qsrc + (a_lo + rr - g_lo + p_lo) * RSTR;
+#pragma unroll
+                                for (int u = 0; u < T; u++) va[k][u] = src[u];
+                            }
+#pragma unroll
+                            for (int k = 0; k < KB; k++) {
+                                if (k * NLQ >= nb * NJG) break;
+                                const int m0 = om + k * NLQ, m = m0 < nb * NJG ? m0 : 0;
+                                const int nbd = nb > 0 ? nb : 1;
+                                const int rr = m % nbd, grp = m / nbd;
+                                const double* __restrict__ src = qsrc + (b_lo + rr - g_lo + p_lo) * RSTR + grp;
+#pragma unroll
+                                for (int u = 0; u < NFI; u++) vb[k][u] = src[u * NJG];
+                            }
+#pragma unroll
+                            for (int k = 0; k < KC; k++) {
+                                if (k * NLQ >= nc * NFI) break;
+                                const int m0 = om + k * NLQ, m = m0 < nc * NFI ? m0 : 0;
+                                const int ncd = nc > 0 ? nc : 1;
+                                const int rr = m % ncd, grp = m / ncd;
+                                const double* __restrict__ src = qsrc + (c_lo + rr - g_lo + p_lo) * RSTR + grp * NJG;
+#pragma unroll
+                                for (int u = 0; u < NJG; u++) vc[k][u] = src[u];
+                            }
+                            // ---- pairwise sums + atomics
+#pragma unroll
+                            for (int k = 0; k < KA; k++) {
+                                if (k * NLQ >= na) break;
+#pragma unroll
+                                for (int w = 1; w < T; w *= 2)
+#pragma unroll
+                                    for (int u = 0; u + w < T; u += 2 * w) va[k][u] += va[k][u + w];
+                                const int m = om + k * NLQ, e = a_lo + m;                    // J_kl[cl][kk], e = kk * NFL + cl
+                                if (oq_ok && m < na) lds_add(sJkl + bJkl + (e % NFL) * WK + e / NFL, va[k][0]);
+                            }
+#pragma unroll
+                            for (int k = 0; k < KB; k++) {
+                                if (k * NLQ >= nb * NJG) break;
+#pragma unroll
+                                for (int w = 1; w < NFI; w *= 2)
+#pragma unroll
+                                    for (int u = 0; u + w < NFI; u += 2 * w) vb[k][u] += vb[k][u + w];
+                                const int m = om + k * NLQ;
+                                const int nbd = nb > 0 ? nb : 1;
+                                const int rr = m % nbd, grp = m / nbd;
+                                const int eb = b_lo + rr - OB, eb2 = eb - NE1;    // K_jk[e][kk] (e * CW + kk) or K_jl[e][cl] (NE1 + e * NFL + cl) of j component grp * EJ + e
+                                double* dst = eb < NE1 ? sKjk + bKjk + (grp * EJ + eb / CW) * WK + eb % CW
+                                                       : sKjl + bKjl + (grp * EJ + eb2 / NFL) * WL + eb2 % NFL;
+                                if (oq_ok && m < nb * NJG) lds_add(dst, vb[k][0]);
+                            }
+#pragma unroll
+                            for (int k = 0; k < KC; k++) {
+                                if (k * NLQ >= nc * NFI) break;
+#pragma unroll
+                                for (int w = 1; w < NJG; w *= 2)
+#pragma unroll
+                                    for (int u = 0; u + w < NJG; u += 2 * w) vc[k][u] += vc[k][u + w];
+                                const int m = om + k * NLQ;
+                                const int ncd = nc > 0 ? nc : 1;
+                                const int rr = m % ncd, grp = m / ncd;
+                                const int ec = c_lo + rr - OC;
+                                double* dst = ec < NE3 ? sKik + bKik + grp * WK + ec : sKil + bKil + grp * WL + (ec - NE3);
+                                if (oq_ok && m < nc * NFI) lds_add(dst, vc[k][0]);
+                            }
+                        }
+#else
 #pragma unroll
                         for (int ps = 0; ps < NPASS; ps++) {
                             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2497,15 +2868,15 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                 if (n > 0) {
                                     const int nd = n > 0 ? n : 1;
 #pragma unroll
-                                    for (int k = 0; k < (nd * GW * NFJ + 63) / 64; k++) {
+                                    for (int k = 0; k < (nd * GW * NJG + 63) / 64; k++) {
                                         const int task = lane + 64 * k, rr = task % nd, rest = task / nd;
-                                        const int grp = rest % NFJ, qs = rest / NFJ;
+                                        const int grp = rest % NJG, qs = rest / NJG;
                                         const int qo = (wave * GW + qs) * per + step;
-                                        if (task < n * GW * NFJ && qo < nact) {
+                                        if (task < n * GW * NJG && qo < nact) {
                                             const double* __restrict__ src = red + (lo + rr - p_lo) * RSTR + qs * T + grp;
                                             double v[NFI];
 #pragma unroll
-                                            for (int u = 0; u < NFI; u++) v[u] = src[u * NFJ];
+                                            for (int u = 0; u < NFI; u++) v[u] = src[u * NJG];
                                             const int qd2 = s_act[qo];
                                             const int a2 = qd2 % TSI, b2 = (qd2 / TSI) % TSJ, d2 = (qd2 / (TSI * TSJ)) % TSL;
                                             const int c2 = QC(qd2 / (TSI * TSJ * TSL), a2, b2, d2);
@@ -2513,8 +2884,10 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                             double sum = 0;
 #pragma unroll
                                             for (int u = 0; u < NFI; u++) sum += v[u];
-                                            double* dst = eb < NE1 ? sKjk + (b2 * NFJ + grp) * WK + c2 * NFK + CH * CW + eb
-                                                                   : sKjl + (b2 * NFJ + grp) * WL + d2 * NFL + (eb - NE1);
+                                            // row eb = K_jk[e][kk] (e * CW + kk) or K_jl[e][cl] (NE1 + e * NFL + cl) of j component grp * EJ + e
+                                            const int eb2 = eb - NE1;
+                                            double* dst = eb < NE1 ? sKjk + (b2 * NFJ + grp * EJ + eb / CW) * WK + c2 * NFK + CH * CW + eb % CW
+                                                                   : sKjl + (b2 * NFJ + grp * EJ + eb2 / NFL) * WL + d2 * NFL + eb2 % NFL;
                                             lds_add(dst, sum);
                                         }
                                     }
@@ -2531,17 +2904,17 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                         const int grp = rest % NFI, qs = rest / NFI;
                                         const int qo = (wave * GW + qs) * per + step;
                                         if (task < n * GW * NFI && qo < nact) {
-                                            const double* __restrict__ src = red + (lo + rr - p_lo) * RSTR + qs * T + grp * NFJ;
-                                            double v[NFJ];
+                                            const double* __restrict__ src = red + (lo + rr - p_lo) * RSTR + qs * T + grp * NJG;
+                                            double v[NJG];
 #pragma unroll
-                                            for (int u = 0; u < NFJ; u++) v[u] = src[u];
+                                            for (int u = 0; u < NJG; u++) v[u] = src[u];
                                             const int qd2 = s_act[qo];
                                             const int a2 = qd2 % TSI, b2 = (qd2 / TSI) % TSJ, d2 = (qd2 / (TSI * TSJ)) % TSL;
                                             const int c2 = QC(qd2 / (TSI * TSJ * TSL), a2, b2, d2);
                                             const int ec = lo + rr - OC;
                                             double sum = 0;
 #pragma unroll
-                                            for (int u = 0; u < NFJ; u++) sum += v[u];
+                                            for (int u = 0; u < NJG; u++) sum += v[u];
                                             double* dst = ec < NE3 ? sKik + (a2 * NFI + grp) * WK + c2 * NFK + CH * CW + ec
                                                                    : sKil + (a2 * NFI + grp) * WL + d2 * NFL + (ec - NE3);
                                             lds_add(dst, sum);
@@ -2550,6 +2923,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                 }
                             }
                         }
+#endif
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
 #if !WSYNC
@@ -2663,7 +3037,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     }
 #if STAMPS
     if (tid == 0 && counter) {
-        for (int k = 0; k < 14; k++) atomicAdd(counter - 1 - k, st_acc[k]);
+        for (int k = 0; k < 15; k++) atomicAdd(counter - 1 - k, st_acc[k]);
         atomicAdd(counter - 16, 1ull);
     }
 #endif

@@ -226,6 +226,7 @@ def test_ket_chunks_and_workgroup_splits(monkeypatch):
 ORED, PAROOT, NDM2 = 1 << 18, 1 << 19, 1 << 20        # include/jqc_hip.h (round 3: owner reduction, per-root phase A, two DMs)
 RSPLIT = lambda code: code << 22                      # (round 4: Rys roots in code + 1 groups through phase A / phase B)
 QUAD = 1 << 24                                        # (round 5: one quartet per quad of lanes; classes with a p shell, <= 4 roots)
+HB, HEJ = 1 << 29, (lambda code: code << 25)          # (round 6: h form -- bra HRR in phase A, lane = (i component, j group of <= 1/2/3/6))
 
 
 @pytest.mark.parametrize("variant", [0x21, 0x21 | 0x100, 0x21 | 0x400, 0x21 | 0x100 | 0x400, 0x22, 0x32, 0x21 | 0x800,
@@ -235,11 +236,13 @@ QUAD = 1 << 24                                        # (round 5: one quartet pe
                                      0xd21 | ORED | RSPLIT(1), 0xd21 | ORED | RSPLIT(2), 0x521 | ORED | RSPLIT(1), 0x121 | ORED | RSPLIT(1),
                                      0xd21 | ORED | PAROOT | RSPLIT(1),
                                      0x1022 | QUAD, 0x1122 | QUAD, 0x0132 | QUAD, 0x1032 | QUAD,
-                                     0x1122 | QUAD | (1 << 25), 0x1122 | QUAD | (2 << 25) | (2 << 27)])      # (+ chunks: 2 over i, 3 over k)
+                                     0x1122 | QUAD | (1 << 25), 0x1122 | QUAD | (2 << 25) | (2 << 27),      # (+ chunks: 2 over i, 3 over k)
+                                     0x521 | ORED | HB, 0x521 | ORED | HB | HEJ(2), 0x121 | ORED | HB | HEJ(1) | RSPLIT(1),
+                                     0x521 | ORED | HB | HEJ(3) | PAROOT])
 def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
     """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
     L2 | single TRR buffer | wave-local steps | j in registers | 2, 4, 8 ket pairs per iteration | owner reduction | per-root
-    phase A | integral-chunk caps | root groups | one quartet per quad of lanes; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.
+    phase A | integral-chunk caps | root groups | one quartet per quad of lanes | h form; include/jqc_hip.h JQC_VARIANT_*): each must give the same J and K.
     Role of the reference's 1q1t == 1qnt cross-check (jqc/backend/data/generate_fragment.py:278-309)."""
     from joltqc_amd.backend import jk as router
     from oracle import dense

@@ -135,7 +135,7 @@ if __name__ == "__main__":
         if os.environ.get("JQC_AB_NOCHECK"):             # timing sweep: the winners are checked in a second run
             chk = "skipped"
         else:
-            r = subprocess.run([sys.executable, __file__, "_check", spec], env=env, capture_output=True, text=True)
+            r = subprocess.run([sys.executable, __file__, "_check", env["JQC_ONLY_CLASS"]], env=env, capture_output=True, text=True)
             chk = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-1500:]
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "class_profile.py"), wl], env=env, capture_output=True, text=True)
         rows = {}
