@@ -194,7 +194,8 @@ def parity_blocks(mol, layout, internal, dm, nthreads):
     """max|dJ|, max|dK| of the timed workload's result against the CPU oracle on a fixed sample of shell blocks in the internal AO
     order (reference bar jqc/pyscf/tests/test_jk.py:83-84: 1e-9 for FP64).  A block needs O(N^2) quartets
     (oracle/dense.py:sampled_blocks), so a handful finishes in seconds where a full oracle build would take hours.  Outside every
-    timed region.  The sample: the highest-l shell against shells of every other angular momentum, plus s / p pairs."""
+    timed region.  The sample: J blocks of neighbouring shell pairs (top-l shell x nearest d / f / ... shell, one low-l pair), K blocks
+    of a top-l shell against random s / mid-l / top-l shells and one low-l pair."""
     from oracle import dense
     T = layout.transform_matrix()
     dm_int = T @ dm.cpu().numpy() @ T.T
@@ -205,14 +206,21 @@ def parity_blocks(mol, layout, internal, dm, nthreads):
     ls = sorted(by_l)
     rng = np.random.default_rng(6)
     pick = lambda l: int(rng.choice(by_l[l]))
+    xyz = np.asarray(layout.packed)[:, :3]
+
+    def near(i, l):                                            # the shell of angular momentum l closest to shell i (J_ij is of the size of
+        c = np.array([s_ for s_ in by_l[l] if s_ != i] or by_l[l])     # the pair's overlap distribution: a far-apart pair would test nothing)
+        return int(c[np.argmin(((xyz[c] - xyz[i]) ** 2).sum(1))])
     top = ls[-1]
     j_pairs, k_pairs = [], []
-    for l in ls:                                                # (f|l) ... blocks + one low-l pair
-        a, b = pick(top), pick(l)
+    for l in ls[-3:]:                                           # J blocks: a top-l shell with its nearest d / f ... neighbour
+        a = pick(top)
+        b = near(a, l)
         j_pairs.append((max(a, b), min(a, b)))
-        a, b = pick(top), pick(l)
-        k_pairs.append((a, b))
-    j_pairs.append(tuple(sorted((pick(ls[0]), pick(ls[min(1, len(ls) - 1)])), reverse=True)))
+    for l in (ls[0], ls[len(ls) // 2], top):                     # K blocks: a top-l shell against a random s / mid-l / top-l shell
+        k_pairs.append((pick(top), pick(l)))
+    a = pick(ls[min(1, len(ls) - 1)])                            # ... and one low-l block of each kind
+    j_pairs.append(tuple(sorted((a, near(a, ls[0])), reverse=True)))
     k_pairs.append((pick(ls[min(1, len(ls) - 1)]), pick(ls[min(1, len(ls) - 1)])))
     vj, vk = internal
     t0 = time.perf_counter()

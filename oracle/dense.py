@@ -88,19 +88,24 @@ def sampled_blocks(layout, dm_int, j_pairs=(), k_pairs=(), omega=None, nthreads=
         return slice(int(loc[s]), int(loc[s + 1]))
 
     outj, outk = {}, {}
-    for (i, j) in j_pairs:
+    # ONE digestion per kind: the union of the blocks' quartet lists, every canonical quartet once (a quartet of one list that also
+    # touches another requested block belongs to that block's own list as well, so the union leaves every requested block complete)
+    if len(j_pairs):
         kk, ll = np.meshgrid(real, real, indexing="ij")
         m = kk >= ll
-        q = _canon(np.full(m.sum(), i), np.full(m.sum(), j), kk[m], ll[m], nb)
+        q = np.concatenate([_canon(np.full(m.sum(), i), np.full(m.sum(), j), kk[m], ll[m], nb) for (i, j) in j_pairs])
+        q = np.unique(q, axis=0)
         vj, _ = O.jk_raw(layout.packed, dm_int, q.astype(np.uint16), omega or 0.0, True, False, nthreads=nthreads)
         v = vj[0] * 2.0
         v = v + v.T
-        outj[(i, j)] = v[rng(i), rng(j)].copy()
-    for (i, k) in k_pairs:
+        for (i, j) in j_pairs:
+            outj[(i, j)] = v[rng(i), rng(j)].copy()
+    if len(k_pairs):
         jj, ll = np.meshgrid(real, real, indexing="ij")
-        q = _canon(np.full(jj.size, i), jj.ravel(), np.full(jj.size, k), ll.ravel(), nb)
+        q = np.concatenate([_canon(np.full(jj.size, i), jj.ravel(), np.full(jj.size, k), ll.ravel(), nb) for (i, k) in k_pairs])
         q = np.unique(q, axis=0)
         _, vk = O.jk_raw(layout.packed, dm_int, q.astype(np.uint16), omega or 0.0, False, True, nthreads=nthreads)
         v = vk[0] + vk[0].T
-        outk[(i, k)] = v[rng(i), rng(k)].copy()
+        for (i, k) in k_pairs:
+            outk[(i, k)] = v[rng(i), rng(k)].copy()
     return outj, outk
