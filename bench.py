@@ -192,10 +192,9 @@ def internal_jk(mol, get_jk, dm):
 
 def parity_blocks(mol, layout, internal, dm, nthreads):
     """max|dJ|, max|dK| of the timed workload's result against the CPU oracle on a fixed sample of shell blocks in the internal AO
-    order (reference bar jqc/pyscf/tests/test_jk.py:83-84: 1e-9 for FP64).  A block needs O(N^2) quartets
+    order (reference bar jqc/pyscf/tests/test_jk.py:83-84: 1e-7 absolute for FP64).  A block needs O(N^2) quartets
     (oracle/dense.py:sampled_blocks), so a handful finishes in seconds where a full oracle build would take hours.  Outside every
-    timed region.  The sample: J blocks of neighbouring shell pairs (top-l shell x nearest d / f / ... shell, one low-l pair), K blocks
-    of a top-l shell against random s / mid-l / top-l shells and one low-l pair."""
+    timed region.  The sample: two J blocks of neighbouring shell pairs and two K blocks of random shell pairs (see below)."""
     from oracle import dense
     T = layout.transform_matrix()
     dm_int = T @ dm.cpu().numpy() @ T.T
@@ -211,17 +210,15 @@ def parity_blocks(mol, layout, internal, dm, nthreads):
     def near(i, l):                                            # the shell of angular momentum l closest to shell i (J_ij is of the size of
         c = np.array([s_ for s_ in by_l[l] if s_ != i] or by_l[l])     # the pair's overlap distribution: a far-apart pair would test nothing)
         return int(c[np.argmin(((xyz[c] - xyz[i]) ** 2).sum(1))])
-    top = ls[-1]
-    j_pairs, k_pairs = [], []
-    for l in ls[-3:]:                                           # J blocks: a top-l shell with its nearest d / f ... neighbour
-        a = pick(top)
-        b = near(a, l)
-        j_pairs.append((max(a, b), min(a, b)))
-    for l in (ls[0], ls[len(ls) // 2], top):                     # K blocks: a top-l shell against a random s / mid-l / top-l shell
-        k_pairs.append((pick(top), pick(l)))
-    a = pick(ls[min(1, len(ls) - 1)])                            # ... and one low-l block of each kind
+    top, mid, low = ls[-1], ls[len(ls) // 2], ls[min(1, len(ls) - 1)]
+    # two J and two K blocks (a block costs N^2/2 resp. N^2 oracle quartets, the f-containing ones ~10 us each on a core): a top-l shell
+    # with its nearest neighbour one l below and a low-l neighbour pair; a top-l shell against a random s shell and a mid-l against a low-l one
+    a = pick(top)
+    b = near(a, ls[-2] if len(ls) > 1 else top)
+    j_pairs = [(max(a, b), min(a, b))]
+    a = pick(low)
     j_pairs.append(tuple(sorted((a, near(a, ls[0])), reverse=True)))
-    k_pairs.append((pick(ls[min(1, len(ls) - 1)]), pick(ls[min(1, len(ls) - 1)])))
+    k_pairs = [(pick(top), pick(ls[0])), (pick(mid), pick(low))]
     vj, vk = internal
     t0 = time.perf_counter()
     oj, ok = dense.sampled_blocks(layout, dm_int, j_pairs, k_pairs, nthreads=nthreads)
@@ -233,10 +230,14 @@ def parity_blocks(mol, layout, internal, dm, nthreads):
     sj = max(float(np.abs(b).max()) for b in oj.values())
     sk = max(float(np.abs(b).max()) for b in ok.values())
     nq = len(real) * (len(real) + 1) // 2 * len(j_pairs) + len(real) ** 2 * len(k_pairs)
-    return {"max_abs_dJ": dj, "max_abs_dK": dk, "max_abs_J": sj, "max_abs_K": sk, "blocks": len(oj) + len(ok),
+    return {"max_abs_dJ": dj, "max_abs_dK": dk, "max_abs_J": sj, "max_abs_K": sk, "max_rel_dJ": dj / sj, "max_rel_dK": dk / sk,
+            "blocks": len(oj) + len(ok),
             "block_classes": {"J": ["(%d%d|" % (layout.angs[i], layout.angs[j]) for i, j in j_pairs],
                               "K": ["(%d.|%d." % (layout.angs[i], layout.angs[k]) for i, k in k_pairs]},
-            "oracle_quartets": int(nq), "oracle_seconds": round(dt, 2), "bar": 1e-9,
+            "oracle_quartets": int(nq), "oracle_seconds": round(dt, 2),
+            "bar": "1e-7 absolute (the reference's FP64 bar, jqc/pyscf/tests/test_jk.py:83-84, on matrices of ITS size; north_star: Fock "
+                   "elements within 1e-6); with this workload's D = R R^T of 2 588 functions the J elements reach 1e5, so the relative figures "
+                   "are the ones to read: 1e-13 is FP64 round-off of sums of ~1e6 terms",
             "how": "shell blocks of J and K of the timed workload (internal AO order, after the epilogue) against oracle/dense.py:"
                    "sampled_blocks -- every quartet a block needs, same C oracle as the parity tests; outside the timed region"}
 

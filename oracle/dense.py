@@ -70,6 +70,15 @@ def _canon(i, j, k, l, nb):
     return np.stack([np.where(sw, k, i), np.where(sw, l, j), np.where(sw, i, k), np.where(sw, j, l)], 1)
 
 
+def _unique_rows(q):
+    """Distinct rows of an integer [n, 4] array of shell indices < 65536 (one 64-bit key per row: far faster than np.unique(axis=0))."""
+    q = q.astype(np.uint64)
+    key = (q[:, 0] << np.uint64(48)) | (q[:, 1] << np.uint64(32)) | (q[:, 2] << np.uint64(16)) | q[:, 3]
+    key = np.unique(key)
+    return np.stack([(key >> np.uint64(48)) & np.uint64(0xffff), (key >> np.uint64(32)) & np.uint64(0xffff),
+                     (key >> np.uint64(16)) & np.uint64(0xffff), key & np.uint64(0xffff)], 1).astype(np.uint16)
+
+
 def sampled_blocks(layout, dm_int, j_pairs=(), k_pairs=(), omega=None, nthreads=1):
     """Shell blocks of J and K in the INTERNAL (sorted, split, Cartesian) AO order, each from its own complete quartet list --
     O(N^2) quartets per block instead of the O(N^4) of a full build: the checker of bench.py's parity figure at sizes where
@@ -93,8 +102,7 @@ def sampled_blocks(layout, dm_int, j_pairs=(), k_pairs=(), omega=None, nthreads=
     if len(j_pairs):
         kk, ll = np.meshgrid(real, real, indexing="ij")
         m = kk >= ll
-        q = np.concatenate([_canon(np.full(m.sum(), i), np.full(m.sum(), j), kk[m], ll[m], nb) for (i, j) in j_pairs])
-        q = np.unique(q, axis=0)
+        q = _unique_rows(np.concatenate([_canon(np.full(m.sum(), i), np.full(m.sum(), j), kk[m], ll[m], nb) for (i, j) in j_pairs]))
         vj, _ = O.jk_raw(layout.packed, dm_int, q.astype(np.uint16), omega or 0.0, True, False, nthreads=nthreads)
         v = vj[0] * 2.0
         v = v + v.T
@@ -102,8 +110,7 @@ def sampled_blocks(layout, dm_int, j_pairs=(), k_pairs=(), omega=None, nthreads=
             outj[(i, j)] = v[rng(i), rng(j)].copy()
     if len(k_pairs):
         jj, ll = np.meshgrid(real, real, indexing="ij")
-        q = np.concatenate([_canon(np.full(jj.size, i), jj.ravel(), np.full(jj.size, k), ll.ravel(), nb) for (i, k) in k_pairs])
-        q = np.unique(q, axis=0)
+        q = _unique_rows(np.concatenate([_canon(np.full(jj.size, i), jj.ravel(), np.full(jj.size, k), ll.ravel(), nb) for (i, k) in k_pairs]))
         _, vk = O.jk_raw(layout.packed, dm_int, q.astype(np.uint16), omega or 0.0, False, True, nthreads=nthreads)
         v = vk[0] + vk[0].T
         for (i, k) in k_pairs:

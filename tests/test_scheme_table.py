@@ -86,6 +86,32 @@ def test_quad_variants_only_where_the_class_supports_them():
     assert router.select_algo((3, 1, 1, 1)) == 0x1001122 | router.VARIANT_QCHUNK(1, 0)
 
 
+def test_h_form_variants_only_where_a_quartet_fits_one_wave():
+    """JQC_VARIANT_HB (bit 29; round 6): row-lane builds with the owner reduction, lane = (bra component i, group of j components).  The
+    j-components-per-lane code (bits 25-26: at most 1 / 2 / 3 / 6, rounded down to a divisor of nf_j) is widened until nf_i * nf_j / EJ
+    fits the 64 lanes of a wave; the bit is dropped where that is impossible or the class is forced to the lane-per-quartet mode."""
+    HB, HEJ, ORED = router.VARIANT_HB, router.VARIANT_HEJ, router.VARIANT_ORED
+    assert router.hb_ej((3, 2, 2, 1), 0x521 | ORED | HB | HEJ(2)) == 3 and router.hb_ej((3, 3, 2, 1), 0x521 | ORED | HB | HEJ(2)) == 2
+    assert router.hb_ej((3, 3, 2, 1), 0x521 | ORED | HB | HEJ(3)) == 5 and router.hb_ej((4, 4, 0, 0), 0x521 | ORED | HB | HEJ(1)) == 1
+    assert router.lanes_per_quartet((3, 2, 2, 1), 0x521 | ORED | HB | HEJ(2)) == 20
+    v = router.forced_variant((3, 3, 2, 2), 0x521 | ORED | HB)              # 100 lanes with one component per lane: widened to two
+    assert v & HB and router.lanes_per_quartet((3, 3, 2, 2), v) == 50
+    v = router.forced_variant((4, 4, 2, 2), 0x521 | ORED | HB)              # (gg|: 225 lanes -> five components per lane, 45 lanes
+    assert v & HB and router.lanes_per_quartet((4, 4, 2, 2), v) == 45
+    assert not router.forced_variant((2, 1, 1, 0), 0x1022 | HB) & HB        # lane-per-quartet request: no h form
+    assert router.forced_variant((3, 2, 2, 1), 0x121 | HB) & ORED           # the form needs the owner reduction
+    with open(os.path.join(ROOT, "joltqc_amd", "data", "gfx950_scheme.json")) as f:
+        sch = json.load(f)
+    n = 0
+    for key, v in sch["fp64"].items():
+        if v & HB:
+            ang = tuple(int(c) for c in key.zfill(4))
+            assert (v & 0xf) == L.ALGO_TILE and v & ORED and not v & 0x800 and router.lanes_per_quartet(ang, v) <= 64, (key, hex(v))
+            assert router.forced_variant(ang, v) == v, (key, hex(v))
+            n += 1
+    assert n >= 13
+
+
 def test_too_many_ket_pairs_degrade_to_fewer(tmp_path, monkeypatch):
     """(dp|ps) with 8 ket pairs per iteration needs > 160 KB of LDS: the router retries with 4 (still the HIP path)."""
     with pytest.raises(RuntimeError):
