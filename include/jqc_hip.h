@@ -67,6 +67,10 @@ extern "C" {
                                     * the ket recurrence and multiplies -- the bra recurrence is no longer redone per lane, root and chunk */
 #define JQC_VARIANT_HEJ(code) ((code) << 25) /* h form: j components per lane = the largest divisor of nf_j that is <= 1 (code 0), 2 (1),
                                     * 3 (2), 6 (3); shares its bits with JQC_VARIANT_QCHUNK (quad builds are lane-per-quartet builds) */
+#define JQC_VARIANT_KW (1 << 30)   /* JQC_ALGO_TILE512 builds with JQC_VARIANT_ORED (no JQC_VARIANT_WSYNC) of classes whose integral block
+                                    * needs TWO chunks over the ket components k: the chunks run on different waves of the 512-thread
+                                    * workgroup at the same time and share the quartets' recurrence arrays -- phase A once per step instead
+                                    * of once per chunk, its jobs dealt over all 512 lanes, every Rys root in one pass */
 #define JQC_VARIANT_MIXED (1 << 21) /* FP64 lane-per-quartet build with BOTH precision windows in one launch: quartets with an
                                       estimate above cut_hi in FP64, those in (cut_lo, cut_hi] in FP32, two per lane as packed
                                       2-vectors (v_pk_fma_f32); one staging / screening / flush per tile pair (replaces the reference's

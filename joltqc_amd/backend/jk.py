@@ -73,6 +73,19 @@ VARIANT_MIXED = 1 << 21        # both precision windows in one launch of an FP64
 VARIANT_HB = 1 << 29           # row-lane mode, h form: bra horizontal recurrence in phase A, lane = (bra component i, group of j components)
 VARIANT_HEJ = lambda code: code << 25      # h form: j components per lane capped at HEJ_CAPS[code] (bits shared with the quad chunk code)
 HEJ_CAPS = (1, 2, 3, 6)
+VARIANT_KW = 1 << 30           # 512-thread row-lane builds: the two k chunks of a class on different waves, sharing the recurrence arrays
+ECAPS = (64, 32, 16, 48)       # integrals per lane and chunk by JQC_VARIANT_ECAP code (jqc_hip.cpp)
+
+
+def k_chunks(ang, v):
+    """Chunks over the ket components k a row-lane build of variant ``v`` walks (jk_tile.hip pick_nch)."""
+    nf = lambda l: (l + 1) * (l + 2) // 2
+    ej = hb_ej(ang, v) if v & VARIANT_HB else nf(ang[1]) if v & 0x800 else 1
+    cap = ECAPS[(v >> 16) & 3]
+    for n in range(1, nf(ang[2]) + 1):
+        if nf(ang[2]) % n == 0 and (nf(ang[2]) // n) * nf(ang[3]) * ej <= cap:
+            return n
+    return nf(ang[2])
 
 
 def hb_ej(ang, v):
@@ -151,7 +164,7 @@ def forced_variant(ang, v):
         # h form: row-lane builds with the owner reduction and a quartet inside one wave; where nf_i * nf_j / EJ exceeds 64 lanes the
         # j-group is widened, and the form is dropped where even that does not fit (or the class is not a row-lane class here)
         v &= ~(0x3 << 27)
-        if (v & 0xf) != _lib.ALGO_TILE:
+        if (v & 0xf) not in (_lib.ALGO_TILE, _lib.ALGO_TILE512):
             v &= ~(VARIANT_HB | (0xf << 25))
         else:
             v = (v | VARIANT_ORED) & ~0x800
@@ -165,6 +178,12 @@ def forced_variant(ang, v):
         v &= ~(0xf000 | VARIANT_MIXED)                # several ket pairs per iteration, strided queue, row-ordered contraction,
                                                       # fused precision phases: lane-per-quartet mode only
     nf = lambda l: (l + 1) * (l + 2) // 2
+    if v & VARIANT_KW:
+        # k chunks on wave groups: 512-thread builds with the owner reduction (a quartet inside one wave), workgroup-wide steps, exactly two chunks
+        if (v & 0xf) != _lib.ALGO_TILE512 or not (v & VARIANT_ORED) or lanes_per_quartet(ang, v) > 64 or k_chunks(ang, v) != 2:
+            v &= ~VARIANT_KW
+        else:
+            v &= ~0x400
     if (v & 0x400) and ((v & 0xf) == _lib.ALGO_TILE1Q or (lanes_per_quartet(ang, v) if v & VARIANT_HB else nf(ang[0]) * nf(ang[1])) > 64):
         v &= ~0x400
     # a fused mixed-precision build reads its two cutoffs differently from every other build (FP64 above cut_hi, FP32 below): it is
@@ -321,7 +340,7 @@ def gen_jk_kernel(ang, do_j=True, do_k=True, rys_lr=False, fp32=False, algo=None
                 # two matrices do not fit even with one ket pair per iteration: one matrix per pass, with the ket pairs per
                 # iteration the variant was tuned for (not the 1 the steps above ended on)
                 algo = (algo & ~VARIANT_NDM2 & ~0x3000) | (want & 0x3000)
-            elif (algo & 0xf) != _lib.ALGO_TILE or (algo & 0xc00) or (algo & VARIANT_HB):
+            elif (algo & 0xf) != _lib.ALGO_TILE or (algo & 0xc00) or (algo & VARIANT_HB) or (algo & VARIANT_KW):
                 algo = _lib.ALGO_TILE | (algo & 0x1f0)
             else:
                 raise

@@ -546,7 +546,7 @@ int jqc_set_kernel_dirs(const char* src_dir, const char* cache_dir)
     for (const char* f : {"jk_common.h", "jk_axis.h"}) h0 = mix(h0, read_file(g_src_dir + "/" + f));
     if (const char* extra = getenv("JQC_EXTRA_DEFS")) h0 = mix(h0, extra);
     // (bump when the build logic of jqc_gen_jk_kernel changes: MINW rebuild loop, ECAP codes, KARG_RELOAD choice, variant bits)
-    h0 = mix(h0, "build-policy-r6:karg-reload-iff-scratch,ored,paroot,ndm2,family-tags,mixed,rsplit,quad,qchunk,hb,hej");
+    h0 = mix(h0, "build-policy-r6b:karg-reload-iff-scratch,ored,paroot,ndm2,family-tags,mixed,rsplit,quad,qchunk,hb,hej,kw");
     // compiler version and option set: register allocation decides which builds pass the gates, so code
     // objects of another hiprtc are other builds -- not reused from the cache, not covered by the verified manifest
     {
@@ -612,6 +612,9 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
     // forms exclude each other: quad = lane-per-quartet builds, h form = row-lane builds)
     const int v_hb = (algo_variant >> 29) & 1, v_hej = v_hb ? (algo_variant >> 25) & 3 : 0;
     const int v_quad = (algo_variant >> 24) & 1, v_qnch = v_hb ? 0 : (algo_variant >> 25) & 3, v_qy = v_hb ? 0 : (algo_variant >> 27) & 3;
+    const int v_kw = (algo_variant >> 30) & 1;
+    if (v_kw && (algo != JQC_ALGO_TILE512 || !((algo_variant >> 18) & 1) || ((algo_variant >> 10) & 1)))
+        return fail(-1, "JQC_VARIANT_KW: 512-thread row-lane builds with the owner reduction and workgroup-wide steps");
     if (v_qnch && !v_quad) return fail(-1, "JQC_VARIANT_QCHUNK: quad builds only");
     if (v_hb && ((algo != JQC_ALGO_TILE && algo != JQC_ALGO_TILE512) || !((algo_variant >> 18) & 1) || ((algo_variant >> 11) & 1) || v_quad))
         return fail(-1, "JQC_VARIANT_HB: row-lane builds with the owner reduction (JQC_VARIANT_ORED), without JQC_VARIANT_CJR");
@@ -664,6 +667,7 @@ int jqc_gen_jk_kernel(int li, int lj, int lk, int ll, int do_j, int do_k, int ry
             d.push_back("-DHB=1");
             d.push_back("-DHEJ=" + std::to_string(hej_cap[v_hej]));
         }
+        if (v_kw) d.push_back("-DKW=1");
         if (v_quad) d.push_back("-DQUAD=1");
         if (v_qnch) {
             static const int nch[4] = {1, 2, 3, 5};

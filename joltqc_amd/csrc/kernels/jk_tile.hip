@@ -163,13 +163,31 @@ static_assert(!HB || !CJR, "HB: CJR is its HEJ = NFJ case");
                     // step loop needs no workgroup barrier and the waves of a workgroup drift apart (LDS atomics of one
                     // overlap the arithmetic of another); costs the 64 % T lanes left over in every wave
 #endif
-constexpr int NWAVE = TBLOCK / 64;
-constexpr int GW = T <= 64 ? 64 / T : 0;          // quartets per wave (WSYNC)
-constexpr bool WMAP = WSYNC || (ORED && !TILE_1Q && T <= 64);     // lane -> quartet map with whole quartets per wave
-constexpr int G = WMAP ? NWAVE * GW : TBLOCK / T;
 #ifndef ECAP
 #define ECAP 64
 #endif
+constexpr int pick_nch()
+{
+    for (int n = 1; n <= NFK; n++)
+        if (NFK % n == 0 && (NFK / n) * NFL * EJ <= ECAP) return n;
+    return NFK;
+}
+constexpr int NCH = pick_nch();
+#ifndef KW
+#define KW 0        // row-lane mode with the owner reduction, classes whose integral block needs NCH > 1 chunks over the ket components k:
+                    // the chunks are worked on by DIFFERENT WAVES at the same time instead of one after the other.  A workgroup has
+                    // NCH x 4 waves (TBLOCK = 256 NCH); wave w owns the quartet slots of wave group w % 4 and chunk w / 4, so the NCH
+                    // waves of a group share the quartets' recurrence arrays in LDS: phase A runs ONCE per (step, primitive combination)
+                    // instead of once per chunk, its jobs dealt over all NCH x 256 lanes, and -- one set of Fock / density tiles per CU
+                    // instead of two -- LDS holds every Rys root of the combination, so one pass instead of RSPLIT.
+#endif
+constexpr int KPARTS = KW ? NCH : 1;              // waves that share a quartet slot group
+constexpr int NWAVE = TBLOCK / 64;
+constexpr int NWAVE_S = NWAVE / KPARTS;           // wave groups that own quartet slots
+constexpr int GW = T <= 64 ? 64 / T : 0;          // quartets per wave (WSYNC)
+constexpr bool WMAP = WSYNC || (ORED && !TILE_1Q && T <= 64);     // lane -> quartet map with whole quartets per wave
+constexpr int G = WMAP ? NWAVE_S * GW : TBLOCK / T;
+static_assert(!KW || (!TILE_1Q && ORED && !WSYNC && T <= 64 && NCH > 1 && NWAVE == 4 * NCH), "KW: owner-reduction builds with workgroup-wide steps, TBLOCK = 256 NCH");
 #ifndef TILE_1Q
 #define TILE_1Q 0   // 1: one quartet per lane inside the tile (small classes); 0: T row lanes per quartet
 #endif
@@ -184,18 +202,12 @@ constexpr int G = WMAP ? NWAVE * GW : TBLOCK / T;
                     // (AGPR spill space) gave wrong results in a few classes (tools/verify_scheme.py)
 #endif
 #ifndef UNROLL_B
-#define UNROLL_B 1   // 1: unroll the root loop of phase B (loads of root r+1 overlap the products of root r)
+#define UNROLL_B (KW ? 0 : 1)   // 1: unroll the root loop of phase B (loads of root r+1 overlap the products of root r); KW builds hold every
+                                // root of a combination in LDS: their unrolled five-root loop spills 540-620 B and runs 5x slower (rolled: 116 B)
 #endif
 #ifndef ST_LDS_MAX
 #define ST_LDS_MAX 40960   // double-buffer the TRR array (phase A of the next combination overlaps phase B) up to this size
 #endif
-constexpr int pick_nch()
-{
-    for (int n = 1; n <= NFK; n++)
-        if (NFK % n == 0 && (NFK / n) * NFL * EJ <= ECAP) return n;
-    return NFK;
-}
-constexpr int NCH = pick_nch();
 constexpr int CW = NFK / NCH;
 constexpr int E = EJ * CW * NFL;                     // integrals per lane and chunk: e = (cj * CW + kk) * NFL + cl
 constexpr int WI = TSI * NFI, WJ = TSJ * NFJ, WK = TSK * NFK, WL = TSL * NFL;
@@ -221,14 +233,19 @@ constexpr int NE0 = DO_J ? CW * NFL : 0, NE1 = DO_K ? EJ * CW : 0, NE2 = DO_K ? 
 constexpr int NE3 = (DO_K && !CJR && !(HB && NJG == 1)) ? CW : 0, NE4 = (DO_K && !CJR && !(HB && NJG == 1)) ? NFL : 0, NPART = NE0 + NE1 + NE2 + NE3 + NE4;
 constexpr int RSTR = 66;
 constexpr int RDBL = 8 / (int)sizeof(real);                                 // reals per double
-constexpr int RG_MIN = NPART < 16 ? NPART : 16;                              // rows the scratch of a wave holds at least
+#ifndef RGMIN_ROWS
+#define RGMIN_ROWS 16
+#endif
+constexpr int RG_MIN = NPART < RGMIN_ROWS ? NPART : RGMIN_ROWS;              // rows the scratch of a wave holds at least
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
 // reals of the TRR array that belong to one wave (WSYNC: its GW slots; otherwise a quarter of the whole array)
 constexpr int WREG0 = WMAP ? GW * TRR_SLOT : (G * TRR_SLOT + NWAVE - 1) / NWAVE;
-constexpr int WREG = USE_ORED ? ((cmax(WREG0, RG_MIN * RSTR * RDBL) + 3) & ~3) : WREG0;
-constexpr int ST_LEN = USE_ORED ? cmax(NWAVE * WREG, NBUF * G * TRR_SLOT) : NBUF * G * TRR_SLOT;
-constexpr int RG = cmin(cmin(WREG / (RSTR * RDBL), NPART), 64);
+// (KW: the KPARTS waves of a slot group split the group's region for their owner-reduction scratch)
+constexpr int WPART = USE_ORED ? ((cmax((WREG0 + KPARTS - 1) / KPARTS, RG_MIN * RSTR * RDBL) + 3) & ~3) : WREG0;
+constexpr int WREG = USE_ORED ? KPARTS * WPART : WREG0;
+constexpr int ST_LEN = USE_ORED ? cmax(NWAVE_S * WREG, NBUF * G * TRR_SLOT) : NBUF * G * TRR_SLOT;
+constexpr int RG = cmin(cmin(WPART / (RSTR * RDBL), NPART), 64);
 constexpr int NPASS = RG > 0 ? (NPART + RG - 1) / RG : 0;
 constexpr int NH = RG > 0 ? 64 / RG : 1;                                    // owner lanes per scratch row (they split the quartets)
 // offset of quartet slot `sl` in the TRR array
@@ -653,6 +670,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wave_s = wave_u % NWAVE_S, kpart = wave_u / NWAVE_S;      // slot-owning wave group, chunk of this wave (KW; otherwise wave, 0)
 #if STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -747,7 +765,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #if !TILE_1Q
     // WMAP: whole quartets per wave (wave-local steps and / or the owner reduction); otherwise quartets packed over the workgroup
     const int qslot = WMAP ? lane / T : 0;
-    const int slot = WMAP ? wave * GW + qslot : tid / T;
+    const int slot = WMAP ? wave_s * GW + qslot : tid / T;
     const int t = WMAP ? lane - qslot * T : tid - slot * T;
     const bool lane_on = WMAP ? qslot < GW : slot < G;
 #if CJR
@@ -1912,7 +1930,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #if WSYNC
                 for (int job = lane; job < GW * NRH; job += 64) {
                     const int sl = job / NRH, rloc = job - sl * NRH, r = rh * NRH + rloc;
-                    const int sa = wave * GW + sl;
+                    const int sa = wave_s * GW + sl;
                     if (RSPLIT > 1 && r >= NROOTS) continue;
 #else
                 for (int job = tid; job < G * NRH; job += TBLOCK) {
@@ -1992,7 +2010,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #if WSYNC
                 for (int job = lane; job < GW * 3 * NRH; job += 64) {
                     const int sl = job / (3 * NRH), rem = job - sl * (3 * NRH);
-                    const int sa = wave * GW + sl;
+                    const int sa = wave_s * GW + sl;
 #else
                 for (int job = tid; job < NJOB; job += TBLOCK) {
                     const int sa = job / (3 * NRH), rem = job - sa * (3 * NRH);
@@ -2075,6 +2093,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 
 #pragma unroll
             for (int CH = 0; CH < NCH; CH++) {
+                if (KW && CH != kpart) continue;          // (KW: this wave's chunk only; the loops of the chunks have the same barriers)
                 // register accumulators carried across consecutive quartets of this lane that share the destination block
                 double jkl_acc[CW * NFL], kjk_acc[EJ * CW], kjl_acc[EJ * NFL];
 #pragma unroll
@@ -2139,8 +2158,10 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         // ---------------- phase B: row lanes: own bra slice, ket HRR, integral accumulation
                         if (on) {
                             const real* __restrict__ myT = sT + (NBUF > 1 ? (item & 1) : 0) * (G * TRR_SLOT) + trr_off(slot);
-#if UNROLL_B
+#if UNROLL_B == 1
 #pragma unroll
+#elif UNROLL_B == 2
+#pragma unroll 2
 #else
 #pragma clang loop unroll(disable)
 #endif
@@ -2425,7 +2446,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                     //      Scratch of this wave: red[row][lane] inside its own part of the TRR array (dead until the next
                     //      phase A).  Row r of a pass is summed by NH owner lanes, each over the quartets qs = h, h + NH, ...
                     {
-                        double* __restrict__ red = (double*)(sT + wave_u * WREG);
+                        double* __restrict__ red = (double*)(sT + wave_s * WREG + kpart * WPART);
                         const int ox = lane % RG, oh = lane / RG;
                         const double* __restrict__ row = red + ox * RSTR + oh * T;
 #if ORED_HOIST
@@ -2436,7 +2457,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma unroll
                         for (int k = 0; k < KN; k++) {
                             const int qs = oh + k * NH;
-                            const int qo = (wave * GW + qs) * per + step;
+                            const int qo = (wave_s * GW + qs) * per + step;
                             okk[k] = oh < NH && qs < GW && qo < nact;
                             const int qd2 = s_act[okk[k] ? qo : 0];
                             const int a2 = qd2 % TSI, b2 = (qd2 / TSI) % TSJ, d2 = (qd2 / (TSI * TSJ)) % TSL;
@@ -2512,7 +2533,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma unroll
                             for (int k = 0; k < (GW + NH - 1) / NH; k++) {
                                 const int qs = oh + k * NH;
-                                const int qo = (wave * GW + qs) * per + step;
+                                const int qo = (wave_s * GW + qs) * per + step;
                                 if (own && qs < GW && qo < nact) {
                                     double v[T];
 #pragma unroll
@@ -2697,14 +2718,14 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                         //      NFJ lanes of one ci (type C).  Same scratch as above: red[row][lane] of this wave.
                         constexpr int rg = RG > 0 ? RG : 1;
                         constexpr int OB = NE0, OC = NE0 + NE1 + NE2;
-                        double* __restrict__ red = (double*)(sT + wave_u * WREG);
+                        double* __restrict__ red = (double*)(sT + wave_s * WREG + kpart * WPART);
 #if ORED_HOIST
                         // Owner lanes are tied to ONE quartet slot of the wave (lane % GW) for the whole step: its destination blocks are decoded
                         // once; lane / GW enumerates the (row, group) sums of a pass.  Per pass: every read first, pairwise sums, atomics last.
                         constexpr int gw = GW > 0 ? GW : 1;
                         constexpr int NLQ = 64 / gw;                      // owner lanes per quartet slot
                         const int oq = lane % gw, om = lane / gw;
-                        const int qo_ = (wave * gw + oq) * per + step;
+                        const int qo_ = (wave_s * gw + oq) * per + step;
                         const bool oq_ok = om < NLQ && qo_ < nact;
                         int bJkl, bKjk, bKjl, bKik, bKil;
                         {
@@ -2844,7 +2865,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
 #pragma unroll
                                     for (int k = 0; k < (nd * GW + 63) / 64; k++) {
                                         const int task = lane + 64 * k, rr = task % nd, qs = task / nd;
-                                        const int qo = (wave * GW + qs) * per + step;
+                                        const int qo = (wave_s * GW + qs) * per + step;
                                         if (task < n * GW && qo < nact) {
                                             const double* __restrict__ src = red + (lo + rr - p_lo) * RSTR + qs * T;
                                             double v[T];
@@ -2871,7 +2892,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                     for (int k = 0; k < (nd * GW * NJG + 63) / 64; k++) {
                                         const int task = lane + 64 * k, rr = task % nd, rest = task / nd;
                                         const int grp = rest % NJG, qs = rest / NJG;
-                                        const int qo = (wave * GW + qs) * per + step;
+                                        const int qo = (wave_s * GW + qs) * per + step;
                                         if (task < n * GW * NJG && qo < nact) {
                                             const double* __restrict__ src = red + (lo + rr - p_lo) * RSTR + qs * T + grp;
                                             double v[NFI];
@@ -2902,7 +2923,7 @@ KNAME(const int nao, const real* __restrict__ basis, const real* __restrict__ dm
                                     for (int k = 0; k < (nd * GW * NFI + 63) / 64; k++) {
                                         const int task = lane + 64 * k, rr = task % nd, rest = task / nd;
                                         const int grp = rest % NFI, qs = rest / NFI;
-                                        const int qo = (wave * GW + qs) * per + step;
+                                        const int qo = (wave_s * GW + qs) * per + step;
                                         if (task < n * GW * NFI && qo < nact) {
                                             const double* __restrict__ src = red + (lo + rr - p_lo) * RSTR + qs * T + grp * NJG;
                                             double v[NJG];

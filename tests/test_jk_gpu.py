@@ -227,6 +227,7 @@ ORED, PAROOT, NDM2 = 1 << 18, 1 << 19, 1 << 20        # include/jqc_hip.h (round
 RSPLIT = lambda code: code << 22                      # (round 4: Rys roots in code + 1 groups through phase A / phase B)
 QUAD = 1 << 24                                        # (round 5: one quartet per quad of lanes; classes with a p shell, <= 4 roots)
 HB, HEJ = 1 << 29, (lambda code: code << 25)          # (round 6: h form -- bra HRR in phase A, lane = (i component, j group of <= 1/2/3/6))
+KW = 1 << 30                                          # (round 6: the two k chunks of a class on different waves of a 512-thread workgroup)
 
 
 @pytest.mark.parametrize("variant", [0x21, 0x21 | 0x100, 0x21 | 0x400, 0x21 | 0x100 | 0x400, 0x22, 0x32, 0x21 | 0x800,
@@ -237,8 +238,8 @@ HB, HEJ = 1 << 29, (lambda code: code << 25)          # (round 6: h form -- bra 
                                      0xd21 | ORED | PAROOT | RSPLIT(1),
                                      0x1022 | QUAD, 0x1122 | QUAD, 0x0132 | QUAD, 0x1032 | QUAD,
                                      0x1122 | QUAD | (1 << 25), 0x1122 | QUAD | (2 << 25) | (2 << 27),      # (+ chunks: 2 over i, 3 over k)
-                                     0x521 | ORED | HB, 0x521 | ORED | HB | HEJ(2), 0x121 | ORED | HB | HEJ(1) | RSPLIT(1),
-                                     0x521 | ORED | HB | HEJ(3) | PAROOT])
+                                     0x521 | ORED | HB, 0x521 | ORED | HB | HEJ(2), 0x121 | ORED | HB | HEJ(1) | RSPLIT(1) | PAROOT,
+                                     0x923 | ORED | KW])      # (k chunks on wave groups: the bit is kept where a class has two chunks)
 def test_every_kernel_variant_of_the_scheme_table(monkeypatch, variant):
     """The gfx950 scheme table picks one of these variants per class (algorithm | waves per SIMD | Rys table through
     L2 | single TRR buffer | wave-local steps | j in registers | 2, 4, 8 ket pairs per iteration | owner reduction | per-root

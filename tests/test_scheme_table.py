@@ -28,7 +28,9 @@ def test_every_class_up_to_g_has_an_entry_and_obeys_the_build_rules():
         for ang in _classes(4):
             v = sch[prec].get(router.class_key(ang))
             assert v is not None, (prec, ang)
-            assert (v & 0xf) in (L.ALGO_TILE, L.ALGO_TILE1Q), (prec, ang, hex(v))
+            assert (v & 0xf) in (L.ALGO_TILE, L.ALGO_TILE1Q) or ((v & 0xf) == L.ALGO_TILE512 and v & router.VARIANT_KW), (prec, ang, hex(v))
+            if v & router.VARIANT_KW:      # k chunks on wave groups: exactly two chunks, a quartet inside one wave
+                assert router.k_chunks(ang, v) == 2 and router.forced_variant(ang, v) == v, (prec, ang, hex(v))
             assert autotune.allowed(v), (prec, ang, hex(v))         # no banned register allocation in the table
             if (v & 0xf) == L.ALGO_TILE1Q:
                 # one lane per quartet up to 200 integrals; the quad form a third of up to 330 per lane, in chunks above 180
