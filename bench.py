@@ -57,7 +57,11 @@ def benzene_atoms():
 
 
 def load_workload(name):
+    """``name`` = benzene | benzene-spdfg | <xyz name under joltqc_amd/data/molecules>[@<basis>] (default basis def2-tzvpp; e.g.
+    ``0425-globular-nitrogenous@def2-svp`` = the size and basis of BASELINE config 5)."""
     from joltqc_amd.gto import mole
+    name, _, basis = name.partition("@")
+    basis = basis or "def2-tzvpp"
     if name == "benzene":
         return mole.Mole(atom=benzene_atoms(), basis="def2-tzvpp"), "benzene C6H6 RHF/def2-TZVPP J+K"
     if name == "benzene-spdfg":
@@ -70,7 +74,7 @@ def load_workload(name):
     atoms = mole.read_xyz(path)
     el = [ln.split()[0] for ln in atoms.splitlines() if ln.strip()]
     formula = "".join(f"{e}{el.count(e)}" for e in sorted(set(el), key=lambda e: (e != "C", e != "H", e)))
-    return mole.Mole(atom=atoms, basis="def2-tzvpp"), f"{name} ({formula}, {len(el)} atoms) RHF/def2-TZVPP J+K"
+    return mole.Mole(atom=atoms, basis=basis), f"{name} ({formula}, {len(el)} atoms) RHF/{basis.replace('def2-', 'def2-').upper().replace('DEF2', 'def2')} J+K"
 
 
 def sample_quartets(layout, per_class, n, rng):
