@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: GPU gates beyond the driver-run suite's time budget (run with -m slow on the round's final GPU pass)")
 
 
 # Order of the GPU suite under ``-x``: the cheap per-class oracle gates first, the full-size BASELINE configurations (minutes each,

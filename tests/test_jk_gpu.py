@@ -377,7 +377,9 @@ def test_every_angular_class_against_the_oracle(mode, monkeypatch):
         # (three atoms 2-3 Bohr apart and a density of O(10) elements: the estimates Q_ij Q_kl |D| of this system lie around 1e0 - 1e2)
         cut64, tol = (1e20, 2e-5) if mode == "fused32" else (30.0, 2e-5)
     bad, nclass, nfused, nboth = [], 0, 0, 0
-    lmax = 2 if dm.ndim == 3 and dm.shape[0] == 3 else 4      # (three matrices: s..d -- the pair builds of every class run in jk_2dm, the odd-tail logic is the same for f, g)
+    # (three matrices: s..d in the driver-run suite -- the pair builds of every class run in jk_2dm, the odd-tail logic is the same for f, g;
+    #  the full s..g three-matrix gate is tests/test_slow_gates.py, run with -m slow on the round's final GPU pass)
+    lmax = 2 if dm.ndim == 3 and dm.shape[0] == 3 and os.environ.get("JQC_TEST_FULL_3DM") != "1" else 4
     get_jk = jkmod.generate_jk_kernel(lay, cutoff_fp64=cut64, cutoff_fp32=1e-13)
     try:
         for li in range(lmax + 1):
