@@ -70,6 +70,18 @@ def ecp_arrays(mol):
 SCREEN_EXPONENT = 46.0      # tasks whose integrand is below exp(-46) = 1e-20 of its prefactors everywhere are skipped
 
 
+def _screened_pairs(rows_a, parents_a, rows_b, parents_b, packed, amin, centre, z, k):
+    """(row a, row b, ECP atom k) triples that pass the distance bound of ``screen_tasks`` -- rows = shell-table rows (auxiliary shells carry
+    their parent's centre and most diffuse exponent: ``parents_*``), vectorised: int32 [n, 3]."""
+    da = np.linalg.norm(packed[parents_a, :3] - centre, axis=1)
+    db = np.linalg.norm(packed[parents_b, :3] - centre, axis=1)
+    aa, ab = amin[parents_a], amin[parents_b]
+    bound = ((aa * da * da)[:, None] + (ab * db * db)[None, :]
+             - np.add.outer(aa * da, ab * db) ** 2 / (np.add.outer(aa, ab) + z))
+    ia, ib = np.nonzero(bound <= SCREEN_EXPONENT)
+    return np.stack([rows_a[ia], rows_b[ib], np.full(ia.size, k)], 1).astype(np.int32).reshape(-1, 3)
+
+
 def screen_tasks(layout, shells, xyz, terms, loc):
     """(shell i <= shell j, ECP atom k) triples worth evaluating.  The reference's make_ecp_tasks keeps every triple ("TODO: Add
     screening here", ecp.py:1355); the potential is short-ranged, so for a large molecule almost all of them are empty.  Bound: with
@@ -198,7 +210,9 @@ def get_ecp_ip(mol_or_basis_layout, ip_type="ip", ecp_atoms=None, precision="fp6
     # the distance screening of the value integrals, shell by shell (an auxiliary shell has its parent's centre and exponents)
     parent = {plus_of[int(s)][0]: int(s) for s in shells}
     parent.update({minus_of[int(s)][0]: int(s) for s in shells if int(s) in minus_of})
-    amin = {int(s): packed[s, 5:5 + 2 * int(packed[s, 10]):2].min() for s in shells}
+    amin_arr = np.zeros(packed.shape[0])
+    for s in shells:
+        amin_arr[s] = packed[s, 5:5 + 2 * int(packed[s, 10]):2].min()
     r, w = radial_grid(nr)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     tab_d, loc_d, terms_d, xyz_d, r_d, w_d, ylm_d = t(table), t(loc), t(terms), t(xyz), t(r), t(w), t(ylm_table())
@@ -208,19 +222,14 @@ def get_ecp_ip(mol_or_basis_layout, ip_type="ip", ecp_atoms=None, precision="fp6
     for n, atom in enumerate(want):
         k = ecp_index[atom]
         z = float(terms[loc[k]:loc[k + 1], 2].min())
-        tasks = []
-        for ia in aux:
-            sa = parent[ia]
-            da = float(np.linalg.norm(packed[sa, :3] - xyz[k]))
-            for sb in shells:
-                db = float(np.linalg.norm(packed[sb, :3] - xyz[k]))
-                a_, b_ = amin[sa], amin[int(sb)]
-                if a_ * da * da + b_ * db * db - (a_ * da + b_ * db) ** 2 / (a_ + b_ + z) <= SCREEN_EXPONENT:
-                    tasks.append((ia, int(sb), k))
+        # (vectorised like screen_tasks: one distance vector per side, the bound as an outer sum -- advisor finding of round 5: the
+        #  Python double loop cost tens of seconds per ECP atom at 100 atoms)
+        tasks = _screened_pairs(np.asarray(aux), np.asarray([parent[ia] for ia in aux]), np.asarray(shells), np.asarray(shells),
+                                packed, amin_arr, xyz[k], z, k)
         mat = torch.zeros((ntot + 1, ntot), dtype=torch.float64, device=dev)
-        if tasks:
+        if len(tasks):
             tk = t(np.asarray(tasks, dtype=np.int32))
-            _lib.check(_lib.lib().jqc_ecp_scalar(tab_d.data_ptr(), ntot, tk.data_ptr(), len(tasks), xyz_d.data_ptr(), loc_d.data_ptr(),
+            _lib.check(_lib.lib().jqc_ecp_scalar(tab_d.data_ptr(), ntot, tk.data_ptr(), int(tasks.shape[0]), xyz_d.data_ptr(), loc_d.data_ptr(),
                                                  terms_d.data_ptr(), r_d.data_ptr(), w_d.data_ptr(), int(nr), ylm_d.data_ptr(),
                                                  mat.data_ptr(), 0, 5, _lib.stream_ptr()))
         cart = torch.stack([wm_d[d][:, None] * mat[im_d[d], :nao] - 2.0 * mat[ip_d[d], :nao] for d in range(3)])
@@ -369,7 +378,9 @@ def get_ecp_ipip(mol_or_basis_layout, ip_type="ipipv", ecp_atoms=None, precision
     r, w = radial_grid(nr)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     tab_d, loc_d, terms_d, xyz_d, r_d, w_d, ylm_d = t(table), t(loc), t(terms), t(xyz), t(r), t(w), t(ylm_table())
-    amin = {s: packed[s, 5:5 + 2 * int(packed[s, 10]):2].min() for s in shells}
+    amin_of = np.zeros(packed.shape[0])
+    for s in shells:
+        amin_of[s] = packed[s, 5:5 + 2 * int(packed[s, 10]):2].min()
     bra_rows = [(base_a + where_a[key][0], key[0]) for key in where_a]
     ket_rows = [(base_b + where_b[key][0], key[0]) for key in where_b] if ip_type == "ipvip" else [(s, s) for s in shells]
     ecp_index = {a: k for k, a in enumerate(all_atoms)}
@@ -382,14 +393,12 @@ def get_ecp_ipip(mol_or_basis_layout, ip_type="ipipv", ecp_atoms=None, precision
     for n, atom in enumerate(want):
         k = ecp_index[atom]
         z = float(terms[loc[k]:loc[k + 1], 2].min())
-        dist = {s: float(np.linalg.norm(packed[s, :3] - xyz[k])) for s in shells}
-        tasks = [(ra, rb, k) for ra, pa in bra_rows for rb, pb in ket_rows
-                 if amin[pa] * dist[pa] ** 2 + amin[pb] * dist[pb] ** 2
-                 - (amin[pa] * dist[pa] + amin[pb] * dist[pb]) ** 2 / (amin[pa] + amin[pb] + z) <= SCREEN_EXPONENT]
+        tasks = _screened_pairs(np.asarray([ra for ra, _ in bra_rows]), np.asarray([pa for _, pa in bra_rows]),
+                                np.asarray([rb for rb, _ in ket_rows]), np.asarray([pb for _, pb in ket_rows]), packed, amin_of, xyz[k], z, k)
         mat = torch.zeros((ntot + 1, ntot + 1), dtype=torch.float64, device=dev)
-        if tasks:
+        if len(tasks):
             tk = t(np.asarray(tasks, dtype=np.int32))
-            _lib.check(_lib.lib().jqc_ecp_scalar(tab_d.data_ptr(), ntot + 1, tk.data_ptr(), len(tasks), xyz_d.data_ptr(), loc_d.data_ptr(),
+            _lib.check(_lib.lib().jqc_ecp_scalar(tab_d.data_ptr(), ntot + 1, tk.data_ptr(), int(tasks.shape[0]), xyz_d.data_ptr(), loc_d.data_ptr(),
                                                  terms_d.data_ptr(), r_d.data_ptr(), w_d.data_ptr(), int(nr), ylm_d.data_ptr(),
                                                  mat.data_ptr(), 0, lmax_shell, _lib.stream_ptr()))
         comps = []
