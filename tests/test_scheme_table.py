@@ -114,6 +114,25 @@ def test_h_form_variants_only_where_a_quartet_fits_one_wave():
     assert n >= 13
 
 
+def test_k_chunks_on_wave_groups_only_for_two_chunk_classes():
+    """JQC_VARIANT_KW (bit 30; round 6): 512-thread row-lane builds with the owner reduction whose integral block needs exactly TWO chunks
+    over the ket components k (jk_tile.hip pick_nch, mirrored by router.k_chunks); elsewhere the bit is dropped, and it excludes the
+    wave-local steps."""
+    KW, ORED = router.VARIANT_KW, router.VARIANT_ORED
+    assert router.k_chunks((3, 2, 2, 1), 0x923 | ORED) == 2 and router.k_chunks((3, 1, 2, 1), 0x923 | ORED) == 1     # 108 / 54 integrals per lane
+    assert router.k_chunks((3, 2, 2, 1), 0x10923 | ORED) == 6                                                       # capped at 32 per chunk
+    assert router.k_chunks((3, 2, 2, 1), 0x123 | ORED) == 1                                                          # lane = (ci, cj): 18 per lane
+    v = router.forced_variant((3, 2, 2, 1), 0xd23 | ORED | KW)
+    assert v & KW and not v & 0x400
+    assert not router.forced_variant((3, 1, 2, 1), 0x923 | ORED | KW) & KW          # one chunk
+    assert not router.forced_variant((3, 2, 2, 1), 0x921 | ORED | KW) & KW          # 256-thread workgroups
+    assert not router.forced_variant((3, 3, 3, 3), 0x923 | ORED | KW) & KW          # ten chunks
+    with open(os.path.join(ROOT, "joltqc_amd", "data", "gfx950_scheme.json")) as f:
+        sch = json.load(f)
+    kw = [k for k, v in sch["fp64"].items() if v & KW]
+    assert sorted(kw) == ["2122", "2221", "3122", "3221"], kw
+
+
 def test_too_many_ket_pairs_degrade_to_fewer(tmp_path, monkeypatch):
     """(dp|ps) with 8 ket pairs per iteration needs > 160 KB of LDS: the router retries with 4 (still the HIP path)."""
     with pytest.raises(RuntimeError):
